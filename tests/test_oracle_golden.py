@@ -1,0 +1,200 @@
+"""Pins oracle/canny_oracle.c against every known-answer vector the reference's own test-suite holds
+(tests/utils/test_utils.cpp), against the oracle's committed regression hashes, and proves on the
+CPU the integer-only rules the HIP kernels use for magnitude and angle binning."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+from canny_edge_amd.synth import synth_frame
+
+FLT_EPSILON = float(np.finfo(np.float32).eps)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---- createGaussianKernel: tests/utils/test_utils.cpp:7-45 -------------------------------------
+def test_kernel_sum_one(ref_vectors):
+    case = ref_vectors["gaussian_kernel"][0]
+    k = oracle.gaussian_kernel(case["sigma"])
+    s = np.float32(0)
+    for v in k:                      # float running sum, like the reference test
+        s = np.float32(s + v)
+    assert abs(float(s) - 1.0) < FLT_EPSILON
+
+
+def test_kernel_values(ref_vectors):
+    case = ref_vectors["gaussian_kernel"][1]
+    k = oracle.gaussian_kernel(case["sigma"])
+    assert len(k) == case["window"]
+    for got, want in zip(k, case["expected"]):
+        assert abs(np.float32(want) - got) < FLT_EPSILON
+
+
+def test_kernel_creation_symmetric(ref_vectors):
+    case = ref_vectors["gaussian_kernel"][2]
+    k = oracle.gaussian_kernel(case["sigma"])
+    assert len(k) == case["window"] == 13
+    for i in range(7):
+        assert k[i] == k[12 - i]
+
+
+@pytest.mark.parametrize("sigma,window", [(0.5, 5), (1.0, 7), (1.4, 11), (2.0, 13), (0.3, 3), (2.5, 17)])
+def test_kernel_window_rule(sigma, window):
+    assert len(oracle.gaussian_kernel(sigma)) == window
+
+
+# ---- gaussian on the fixture image: tests/utils/test_utils.cpp:47-104 ---------------------------
+def test_gaussian_fixture_nonzero_in_range(ref_vectors, fixture_image):
+    case = ref_vectors["gaussian_image"][0]
+    out = oracle.gaussian(fixture_image, case["sigma"])
+    assert out.shape == (case["rows"], case["columns"])
+    assert int(out.astype(np.int64).sum()) != 0
+    assert out.min() >= 0 and out.max() <= 255
+
+
+def test_gaussian_constant_image_is_identity():
+    img = np.full((19, 23), 200, dtype=np.uint8)
+    for sigma in (0.5, 1.0, 1.4, 2.0):
+        out = oracle.gaussian(img, sigma)
+        # renormalised borders: a constant image stays constant up to the truncating cast
+        assert set(np.unique(out)) <= {199, 200}
+
+
+# ---- calculateXYGradient: tests/utils/test_utils.cpp:106-208 -----------------------------------
+def test_gradient_vectors(ref_vectors):
+    for case in ref_vectors["gradient"]:
+        img = np.array(case["img"], dtype=np.int16).reshape(case["rows"], case["columns"])
+        gx, gy = oracle.xy_gradient(img)
+        assert gx.ravel().tolist() == case["gx"], case["name"]
+        assert gy.ravel().tolist() == case["gy"], case["name"]
+
+
+# ---- sobelOperator: tests/utils/test_utils.cpp:210-271 -----------------------------------------
+def test_sobel_constant(ref_vectors):
+    case = ref_vectors["sobel"][0]
+    img = np.array(case["img"], dtype=np.int16).reshape(case["rows"], case["columns"])
+    mag, ang = oracle.sobel(img)
+    assert mag.shape == ang.shape == (3, 3)
+    assert not mag.any() and not ang.any()
+
+
+def test_angle_vector(ref_vectors):
+    case = ref_vectors["angle_bins"][0]
+    got = [oracle.angle_bin(x, y) for x, y in zip(case["gx"], case["gy"])]
+    assert got == case["angle"]
+
+
+# ---- nonmaximalSuppression: tests/utils/test_utils.cpp:273-347 ---------------------------------
+def test_nms_vectors(ref_vectors):
+    for case in ref_vectors["nms"]:
+        shape = (case["rows"], case["columns"])
+        out = oracle.nms(np.array(case["grad"], dtype=np.int16).reshape(shape),
+                         np.array(case["angle"], dtype=np.int16).reshape(shape))
+        assert out.ravel().tolist() == case["expected"], case["name"]
+
+
+# ---- findEdgePixels / hysteresis: tests/utils/test_utils.cpp:349-397 ---------------------------
+def test_find_edge_pixels_vector(ref_vectors):
+    case = ref_vectors["find_edge_pixels"][0]
+    shape = (case["rows"], case["columns"])
+    cand = np.array(case["suppress"], dtype=np.int16).reshape(shape)
+    out, _ = oracle.find_edge_pixels(cand, np.zeros(shape, np.uint8), case["start"], case["min"], case["max"])
+    assert out.ravel().tolist() == case["expected"]
+
+
+def test_hysteresis_vector(ref_vectors):
+    case = ref_vectors["hysteresis"][0]
+    shape = (case["rows"], case["columns"])
+    out = oracle.hysteresis(np.array(case["suppress"], dtype=np.int16).reshape(shape), case["min"], case["max"])
+    assert out.ravel().tolist() == case["expected"]
+
+
+def test_hysteresis_directed_quirk():
+    """src/utils.cpp:378,399: `current - width > 0` -- pixel (1,0) never pushes pixel (0,1),
+    while (0,1) does push (1,0)."""
+    a = np.zeros((4, 4), np.int16)
+    a[2, 0] = 200          # strong
+    a[1, 0] = 60           # weak, reached from (2,0)
+    a[0, 1] = 60           # weak, only neighbour in the chain is (1,0) -> stays unreached
+    out = oracle.hysteresis(a, 50, 150)
+    assert out[2, 0] == 255 and out[1, 0] == 255 and out[0, 1] == 0
+    b = np.zeros((4, 4), np.int16)
+    b[0, 2] = 200
+    b[0, 1] = 60
+    b[1, 0] = 60           # reached through (0,1) -> (1,0), which is allowed
+    out = oracle.hysteresis(b, 50, 150)
+    assert out[0, 1] == 255 and out[1, 0] == 255
+
+
+# ---- committed regression pins of the oracle itself -------------------------------------------
+def test_oracle_stage_hashes(oracle_hashes, fixture_image):
+    inputs = {
+        "fixture256_s0.5_50_150": fixture_image,
+        "fixture256_s1.0_50_150": fixture_image,
+        "synth_97x131_seed7_s1.4_50_150": synth_frame(97, 131, 7),
+        "synth_240x320_seed42_s2.0_30_90": synth_frame(240, 320, 42),
+        "synth_64x64_seed3_s0.5_10_50": synth_frame(64, 64, 3),
+    }
+    for name, want in oracle_hashes.items():
+        img = inputs[name]
+        assert _sha(img) == want["input_sha256"], f"{name}: input generator drifted"
+        r = oracle.canny(img, want["sigma"], want["min"], want["max"], stages=True)
+        for plane in ("smoothed", "magnitude", "angle", "nms", "edges"):
+            assert _sha(r[plane]) == want[f"{plane}_sha256"], f"{name}: {plane}"
+        assert int(np.count_nonzero(r["edges"])) == want["edge_pixels"]
+
+
+def test_fixture_counts_match_survey_probe(oracle_hashes):
+    """SURVEY.md 8(c) records what the surveyor measured with the reference's own utils.cpp on the same
+    PIL decode at sigma=1.0, 50/150: 9,952 NMS non-zeros and 2,448 edge pixels."""
+    h = oracle_hashes["fixture256_s1.0_50_150"]
+    assert h["nms_nonzero"] == 9952 and h["edge_pixels"] == 2448
+
+
+# ---- the integer-only rules the HIP kernels use, proven against the oracle's libm path --------
+def _int_angle_rule(gx, gy):
+    """Exact-math binning: with A=gx^2, B=gy^2, P=gx*gy:
+       bin 0   iff 2|P| <= A-B    (|gy| <= |gx| tan 22.5deg; equality only at gx=gy=0)
+       bin 90  iff 2|P| <  B-A    (|gy| >  |gx| tan 67.5deg)
+       else 45 if P > 0 else 135."""
+    gx = gx.astype(np.int64)
+    gy = gy.astype(np.int64)
+    A, B, P = gx * gx, gy * gy, gx * gy
+    out = np.where(P > 0, 45, 135)
+    out = np.where(2 * np.abs(P) < B - A, 90, out)
+    out = np.where(2 * np.abs(P) <= A - B, 0, out)
+    return out.astype(np.uint8)
+
+
+def test_integer_angle_rule_exhaustive():
+    lim = 1020                       # 4*255: the largest |gx|, |gy| a [0,255] plane can produce
+    table = oracle.angle_table(lim)
+    g = np.arange(-lim, lim + 1)
+    gx, gy = np.meshgrid(g, g)       # table[gy+lim, gx+lim]
+    assert np.array_equal(_int_angle_rule(gx, gy), table)
+
+
+def test_float_sqrt_rule_exhaustive():
+    """floor(sqrt(n)) == trunc(sqrtf(n + 0.5f)) for every n = gx^2+gy^2 reachable (n <= 2*1020^2),
+    even if sqrtf is off by one ulp either way (the device's v_sqrt_f32 is a 1-ulp approximation)."""
+    lim = 1020
+    n = np.arange(0, 2 * lim * lim + 1, dtype=np.int64)
+    want = np.floor(np.sqrt(n.astype(np.float64))).astype(np.int64)
+    assert np.array_equal(want * want <= n, np.ones_like(n, bool)) and np.all((want + 1) ** 2 > n)
+    # n + 0.5 is exact in float32 (n < 2^21) and sqrt(n + 0.5) is never representable (2(2n+1) is not a
+    # square), so "within 1 ulp of the true root" means: one of the two float32 values bracketing it.
+    t = np.sqrt(n.astype(np.float64) + 0.5)
+    near = t.astype(np.float32)
+    lo = np.where(near.astype(np.float64) <= t, near, np.nextafter(near, np.float32(-1)))
+    hi = np.nextafter(lo, np.float32(1e9))
+    assert np.all(lo.astype(np.float64) < t) and np.all(hi.astype(np.float64) > t)
+    for probe in (lo, hi):
+        assert np.array_equal(np.trunc(probe).astype(np.int64), want)
+    table = oracle.magnitude_table(lim)
+    g = np.arange(-lim, lim + 1, dtype=np.int64)
+    gx, gy = np.meshgrid(g, g)
+    assert np.array_equal(want[gx * gx + gy * gy].astype(np.int16), table)

@@ -1,0 +1,838 @@
+// canny_capi.hip -- implementation of the C ABI declared in include/canny_hip.h.
+//
+// Host-side runtime around the kernels in canny_kernels.hip: contexts (one device + one stream),
+// device workspaces that grow on demand and are reused across calls, HIP-event stage timers, the
+// hysteresis convergence loop, the stream-overlapped batch path and the per-GPU sharder.
+// There is no CPU implementation behind any of these entry points: without a HIP device every
+// call fails with CANNY_HIP_ERR_NO_DEVICE.
+#include "canny_hip.h"
+#include "canny_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace canny;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) return e;
+        }
+        // grow with a little head-room so slowly growing batches do not reallocate every call
+        size_t want = need + need / 8;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipMalloc(&p, need);
+            want = need;
+        }
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct canny_hip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int last_hyst_iters = 0;
+
+    // device workspaces
+    DevBuf tmp_f32;   // generic Gaussian row-pass plane
+    DevBuf smoothed;  // pipeline: Gaussian output
+    DevBuf plane_s, plane_c, stamps, flags; // hysteresis bit-planes / scheduling words
+    DevBuf io[4];     // staging for the host-pointer stage functions
+    unsigned *host_flags = nullptr; // pinned, 2 words
+
+    // profiling
+    bool prof = false;
+    std::vector<EventPair> pending[CANNY_HIP_STAGE_COUNT];
+    std::vector<EventPair> pool;
+    double total_ms[CANNY_HIP_STAGE_COUNT] = {0};
+    long launches[CANNY_HIP_STAGE_COUNT] = {0};
+};
+
+namespace {
+
+int fail(canny_hip_ctx *ctx, hipError_t e, const char *where)
+{
+    if (ctx) {
+        ctx->last_error = std::string(where) + ": " + hipGetErrorString(e);
+    }
+    (void)hipGetLastError();
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? CANNY_HIP_ERR_NO_DEVICE : CANNY_HIP_ERR_RUNTIME;
+}
+
+#define HIP_TRY(ctx, expr)                                  \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) return fail((ctx), e_, #expr); \
+    } while (0)
+
+int bind(canny_hip_ctx *ctx)
+{
+    if (!ctx) return CANNY_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return CANNY_HIP_OK;
+}
+
+// RAII stage timer: brackets the launches of one stage with events on the launch stream.
+struct StageTimer {
+    canny_hip_ctx *ctx;
+    int stage;
+    EventPair ev{};
+    bool on = false;
+    StageTimer(canny_hip_ctx *c, int s) : ctx(c), stage(s)
+    {
+        if (!ctx->prof) return;
+        if (!ctx->pool.empty()) {
+            ev = ctx->pool.back();
+            ctx->pool.pop_back();
+        } else {
+            if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+        }
+        on = hipEventRecord(ev.a, ctx->stream) == hipSuccess;
+    }
+    ~StageTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, ctx->stream);
+        ctx->pending[stage].push_back(ev);
+    }
+};
+
+// createGaussianKernel, reference src/utils.cpp:77-95, evaluated on the host with the reference's
+// exact expression types: float window rule, expf in float, the 1/(sqrt(2pi) sigma) factor in
+// double, a float running sum and a float divide per tap.  (Built with -ffp-contract=off.)
+int make_taps(float sigma, GaussTaps &t)
+{
+    if (!(sigma > 0.0f) || !std::isfinite(sigma)) return CANNY_HIP_ERR_INVALID;
+    float wf = 1 + 2 * std::ceil(3 * sigma);
+    if (!(wf >= 1.0f) || wf > (float)kMaxWindow) return CANNY_HIP_ERR_UNSUPPORTED;
+    int window = (int)wf;
+    int center = window / 2;
+    float total = 0.0f;
+    for (int i = 0; i < window; i++) {
+        float x = (float)(i - center);
+        float e = expf(-((x * x) / (2 * sigma * sigma)));
+        float tap = (float)((double)e / (std::sqrt(6.2831853) * (double)sigma));
+        t.tap[i] = tap;
+        total += tap;
+    }
+    for (int i = 0; i < window; i++) t.tap[i] /= total;
+    for (int i = window; i < kMaxWindow; i++) t.tap[i] = 0.0f;
+    t.center = center;
+    return CANNY_HIP_OK;
+}
+
+int check_dims(int height, int width, int n_frames)
+{
+    if (height < 1 || width < 1 || n_frames < 1) return CANNY_HIP_ERR_INVALID;
+    if ((long long)height * width > 0x7fffffffLL) return CANNY_HIP_ERR_UNSUPPORTED;
+    if (n_frames > 65535) return CANNY_HIP_ERR_UNSUPPORTED;
+    return CANNY_HIP_OK;
+}
+
+size_t npx(int height, int width, int n_frames) { return (size_t)height * (size_t)width * (size_t)n_frames; }
+
+// ---- device-level stages ------------------------------------------------------------------------
+int dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int h, int w, int n, short *d_out)
+{
+    GaussTaps taps;
+    int rc = make_taps(sigma, taps);
+    if (rc) return rc;
+    StageTimer tm(ctx, CANNY_HIP_STAGE_GAUSSIAN);
+    if (gaussian_march_supported(taps.center, h, w)) {
+        HIP_TRY(ctx, launch_gaussian_march(d_img, d_out, h, w, n, taps, ctx->stream));
+    } else {
+        HIP_TRY(ctx, ctx->tmp_f32.ensure(npx(h, w, n) * sizeof(float)));
+        HIP_TRY(ctx, launch_gaussian_generic(d_img, (float *)ctx->tmp_f32.p, d_out, h, w, n, taps, ctx->stream));
+    }
+    return CANNY_HIP_OK;
+}
+
+int ensure_hyst(canny_hip_ctx *ctx, const HystGeom &g)
+{
+    HIP_TRY(ctx, ctx->plane_s.ensure(g.words() * sizeof(uint64_t)));
+    HIP_TRY(ctx, ctx->plane_c.ensure(g.words() * sizeof(uint64_t)));
+    HIP_TRY(ctx, ctx->stamps.ensure((size_t)g.tiles() * sizeof(unsigned)));
+    HIP_TRY(ctx, ctx->flags.ensure(2 * sizeof(unsigned)));
+    if (!ctx->host_flags) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->host_flags, 2 * sizeof(unsigned)));
+    return CANNY_HIP_OK;
+}
+
+// Runs propagation sweeps until no tile was re-stamped.  flags[0] = last_change, flags[1] = domain.
+int run_propagation(canny_hip_ctx *ctx, const HystGeom &g)
+{
+    uint64_t *S = (uint64_t *)ctx->plane_s.p;
+    const uint64_t *C = (const uint64_t *)ctx->plane_c.p;
+    unsigned *stamp = (unsigned *)ctx->stamps.p;
+    unsigned *flags = (unsigned *)ctx->flags.p;
+    const int kMaxSweeps = 1 << 22;
+    int iter = 0;
+    for (;;) {
+        int chunk = iter == 0 ? 4 : 8;
+        {
+            StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_PROPAGATE);
+            for (int k = 0; k < chunk; k++)
+                HIP_TRY(ctx, launch_hyst_propagate(S, C, stamp, flags, iter + k, g, ctx->stream));
+        }
+        iter += chunk;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->host_flags, flags, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->host_flags[1]) return CANNY_HIP_ERR_DOMAIN;
+        if (ctx->host_flags[0] != (unsigned)iter) break; // nothing scheduled for sweep `iter`
+        if (iter >= kMaxSweeps) return CANNY_HIP_ERR_NO_CONVERGE;
+    }
+    ctx->last_hyst_iters = (int)ctx->host_flags[0] + 1;
+    return CANNY_HIP_OK;
+}
+
+int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int lo, int hi)
+{
+    HystGeom g = make_hyst_geom(h, w, n);
+    int rc = ensure_hyst(ctx, g);
+    if (rc) return rc;
+    unsigned *flags = (unsigned *)ctx->flags.p;
+    HIP_TRY(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), ctx->stream));
+    {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_CLASSIFY);
+        HIP_TRY(ctx, launch_hyst_classify(d_cand, (uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p, g, lo, hi,
+                                          flags + 1, ctx->stream));
+    }
+    rc = run_propagation(ctx, g);
+    if (rc) return rc;
+    {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_FINALIZE);
+        // reached pixels hold EDGE=255 and survive the final `< max_val -> 0` sweep only if 255 >= max_val
+        HIP_TRY(ctx, launch_hyst_finalize(d_cand, (const uint64_t *)ctx->plane_s.p, g, 255 >= hi ? 255 : 0, ctx->stream));
+    }
+    return CANNY_HIP_OK;
+}
+
+int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int lo, int hi, int h, int w, int n,
+              short *d_edges)
+{
+    if (h < 2 || w < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    HIP_TRY(ctx, ctx->smoothed.ensure(npx(h, w, n) * sizeof(short)));
+    short *sm = (short *)ctx->smoothed.p;
+    int rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm);
+    if (rc) return rc;
+    {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+        HIP_TRY(ctx, launch_sobel_nms(sm, d_edges, h, w, n, /*domain8=*/true, ctx->stream));
+    }
+    return dev_hysteresis(ctx, d_edges, h, w, n, lo, hi);
+}
+
+int h2d(canny_hip_ctx *ctx, DevBuf &b, const void *src, size_t bytes)
+{
+    HIP_TRY(ctx, b.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return CANNY_HIP_OK;
+}
+int d2h_sync(canny_hip_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int canny_hip_version(void) { return CANNY_HIP_VERSION; }
+
+const char *canny_hip_status_string(int status)
+{
+    switch (status) {
+    case CANNY_HIP_OK: return "ok";
+    case CANNY_HIP_ERR_INVALID: return "invalid argument";
+    case CANNY_HIP_ERR_UNSUPPORTED: return "unsupported size or window";
+    case CANNY_HIP_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+    case CANNY_HIP_ERR_RUNTIME: return "HIP runtime error";
+    case CANNY_HIP_ERR_DOMAIN: return "input outside the documented numeric domain";
+    case CANNY_HIP_ERR_NO_CONVERGE: return "hysteresis propagation did not converge";
+    default: return "unknown status";
+    }
+}
+
+int canny_hip_device_count(int *count)
+{
+    if (!count) return CANNY_HIP_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        return CANNY_HIP_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_ctx_create(canny_hip_ctx **out, int device)
+{
+    if (!out) return CANNY_HIP_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        return CANNY_HIP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return CANNY_HIP_ERR_INVALID;
+    canny_hip_ctx *ctx = new (std::nothrow) canny_hip_ctx();
+    if (!ctx) return CANNY_HIP_ERR_RUNTIME;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        delete ctx;
+        return CANNY_HIP_ERR_NO_DEVICE;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return CANNY_HIP_OK;
+}
+
+void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->tmp_f32.release();
+    ctx->smoothed.release();
+    ctx->plane_s.release();
+    ctx->plane_c.release();
+    ctx->stamps.release();
+    ctx->flags.release();
+    for (auto &b : ctx->io) b.release();
+    if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
+    for (auto &v : ctx->pending)
+        for (auto &e : v) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+    for (auto &e : ctx->pool) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int canny_hip_ctx_set_stream(canny_hip_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return CANNY_HIP_ERR_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_ctx_device(const canny_hip_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int canny_hip_synchronize(canny_hip_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+const char *canny_hip_last_error(const canny_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+int canny_hip_last_hysteresis_iterations(const canny_hip_ctx *ctx) { return ctx ? ctx->last_hyst_iters : 0; }
+
+// ---- memory helpers -------------------------------------------------------------------------------
+int canny_hip_malloc(canny_hip_ctx *ctx, void **dev_ptr, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!dev_ptr) return CANNY_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return CANNY_HIP_OK;
+}
+int canny_hip_free(canny_hip_ctx *ctx, void *dev_ptr)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipFree(dev_ptr));
+    return CANNY_HIP_OK;
+}
+int canny_hip_host_alloc(canny_hip_ctx *ctx, void **host_ptr, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!host_ptr) return CANNY_HIP_ERR_INVALID;
+    HIP_TRY(ctx, hipHostMalloc(host_ptr, bytes ? bytes : 1));
+    return CANNY_HIP_OK;
+}
+int canny_hip_host_free(canny_hip_ctx *ctx, void *host_ptr)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipHostFree(host_ptr));
+    return CANNY_HIP_OK;
+}
+int canny_hip_memcpy_h2d(canny_hip_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANNY_HIP_OK;
+}
+int canny_hip_memcpy_d2h(canny_hip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    return d2h_sync(ctx, host_dst, dev_src, bytes);
+}
+
+// ---- host-pointer stage functions -----------------------------------------------------------------
+int canny_hip_gaussian_kernel(float sigma, float *taps, int cap, int *window)
+{
+    if (!taps || !window) return CANNY_HIP_ERR_INVALID;
+    GaussTaps t;
+    int rc = make_taps(sigma, t);
+    if (rc) return rc;
+    int w = 2 * t.center + 1;
+    *window = w;
+    if (cap < w) return CANNY_HIP_ERR_INVALID;
+    std::memcpy(taps, t.tap, (size_t)w * sizeof(float));
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_gaussian(canny_hip_ctx *ctx, const unsigned char *img, float sigma, int height, int width, short *result)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!img || !result) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, 1))) return rc;
+    size_t n = npx(height, width, 1);
+    if ((rc = h2d(ctx, ctx->io[0], img, n))) return rc;
+    HIP_TRY(ctx, ctx->io[1].ensure(n * 2));
+    if ((rc = dev_gaussian(ctx, (const unsigned char *)ctx->io[0].p, sigma, height, width, 1, (short *)ctx->io[1].p)))
+        return rc;
+    return d2h_sync(ctx, result, ctx->io[1].p, n * 2);
+}
+
+int canny_hip_xy_gradient(canny_hip_ctx *ctx, const short *img, int height, int width, short *grad_x, short *grad_y)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!img || !grad_x || !grad_y) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, 1))) return rc;
+    if (height < 2 || width < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    size_t n = npx(height, width, 1);
+    if ((rc = h2d(ctx, ctx->io[0], img, n * 2))) return rc;
+    HIP_TRY(ctx, ctx->io[1].ensure(n * 2));
+    HIP_TRY(ctx, ctx->io[2].ensure(n * 2));
+    {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_XY_GRADIENT);
+        HIP_TRY(ctx, launch_xy_gradient((const int16_t *)ctx->io[0].p, (int16_t *)ctx->io[1].p, (int16_t *)ctx->io[2].p,
+                                        height, width, 1, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(grad_x, ctx->io[1].p, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    return d2h_sync(ctx, grad_y, ctx->io[2].p, n * 2);
+}
+
+int canny_hip_sobel(canny_hip_ctx *ctx, const short *img, int height, int width, short *magnitude, short *angle)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!img || !magnitude || !angle) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, 1))) return rc;
+    if (height < 2 || width < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    size_t n = npx(height, width, 1);
+    if ((rc = h2d(ctx, ctx->io[0], img, n * 2))) return rc;
+    HIP_TRY(ctx, ctx->io[1].ensure(n * 2));
+    HIP_TRY(ctx, ctx->io[2].ensure(n * 2));
+    {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL);
+        HIP_TRY(ctx, launch_sobel((const int16_t *)ctx->io[0].p, (int16_t *)ctx->io[1].p, (int16_t *)ctx->io[2].p,
+                                  height, width, 1, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(magnitude, ctx->io[1].p, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    return d2h_sync(ctx, angle, ctx->io[2].p, n * 2);
+}
+
+int canny_hip_nms(canny_hip_ctx *ctx, const short *magnitude, const short *angle, int height, int width, short *result)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!magnitude || !angle || !result) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, 1))) return rc;
+    size_t n = npx(height, width, 1);
+    if ((rc = h2d(ctx, ctx->io[0], magnitude, n * 2))) return rc;
+    if ((rc = h2d(ctx, ctx->io[1], angle, n * 2))) return rc;
+    HIP_TRY(ctx, ctx->io[2].ensure(n * 2));
+    {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_NMS);
+        HIP_TRY(ctx, launch_nms((const int16_t *)ctx->io[0].p, (const int16_t *)ctx->io[1].p, (int16_t *)ctx->io[2].p,
+                                height, width, 1, ctx->stream));
+    }
+    return d2h_sync(ctx, result, ctx->io[2].p, n * 2);
+}
+
+int canny_hip_hysteresis(canny_hip_ctx *ctx, short *edge_candidates, int height, int width, int min_val, int max_val)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!edge_candidates) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, 1))) return rc;
+    size_t n = npx(height, width, 1);
+    if ((rc = h2d(ctx, ctx->io[0], edge_candidates, n * 2))) return rc;
+    if ((rc = dev_hysteresis(ctx, (short *)ctx->io[0].p, height, width, 1, min_val, max_val))) return rc;
+    return d2h_sync(ctx, edge_candidates, ctx->io[0].p, n * 2);
+}
+
+int canny_hip_find_edge_pixels(canny_hip_ctx *ctx, short *edge_candidates, unsigned char *visited, int start,
+                               int min_val, int max_val, int height, int width)
+{
+    (void)max_val; // unused by the reference too (src/utils.cpp:360-427)
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!edge_candidates || !visited) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, 1))) return rc;
+    size_t n = npx(height, width, 1);
+    if (start < 0 || (size_t)start >= n) return CANNY_HIP_ERR_INVALID;
+    if (visited[start]) return CANNY_HIP_OK; // src/utils.cpp:361
+    HystGeom g = make_hyst_geom(height, width, 1);
+    if ((rc = ensure_hyst(ctx, g))) return rc;
+    if ((rc = h2d(ctx, ctx->io[0], edge_candidates, n * 2))) return rc;
+    if ((rc = h2d(ctx, ctx->io[1], visited, n))) return rc;
+    unsigned *flags = (unsigned *)ctx->flags.p;
+    HIP_TRY(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), ctx->stream));
+    HIP_TRY(ctx, launch_fep_classify((const int16_t *)ctx->io[0].p, (const uint8_t *)ctx->io[1].p,
+                                     (uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p, g, start, min_val,
+                                     ctx->stream));
+    if ((rc = run_propagation(ctx, g))) return rc;
+    HIP_TRY(ctx, launch_fep_finalize((int16_t *)ctx->io[0].p, (uint8_t *)ctx->io[1].p, (const uint64_t *)ctx->plane_s.p,
+                                     g, start, min_val, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(edge_candidates, ctx->io[0].p, n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    return d2h_sync(ctx, visited, ctx->io[1].p, n);
+}
+
+int canny_hip_canny(canny_hip_ctx *ctx, const unsigned char *img, float sigma, int min_val, int max_val, int height,
+                    int width, short *edges)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!img || !edges) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, 1))) return rc;
+    size_t n = npx(height, width, 1);
+    if ((rc = h2d(ctx, ctx->io[0], img, n))) return rc;
+    HIP_TRY(ctx, ctx->io[1].ensure(n * 2));
+    if ((rc = dev_canny(ctx, (const unsigned char *)ctx->io[0].p, sigma, min_val, max_val, height, width, 1,
+                        (short *)ctx->io[1].p)))
+        return rc;
+    return d2h_sync(ctx, edges, ctx->io[1].p, n * 2);
+}
+
+int canny_hip_shard_range(int n_frames, int rank, int world, int *begin, int *end)
+{
+    if (!begin || !end || world < 1 || rank < 0 || rank >= world || n_frames < 0) return CANNY_HIP_ERR_INVALID;
+    // contiguous ranges, the first (n_frames % world) shards one frame longer
+    long long q = n_frames / world, r = n_frames % world;
+    long long b = rank * q + std::min<long long>(rank, r);
+    long long e = b + q + (rank < r ? 1 : 0);
+    *begin = (int)b;
+    *end = (int)e;
+    return CANNY_HIP_OK;
+}
+
+// Stream-overlapped batch: the frames are cut into chunks; up to three worker threads, each with its
+// own stream, device workspace and pinned staging, take chunks round-robin so that the H2D copy of
+// one chunk, the kernels of another and the D2H copy of a third are in flight together.
+int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                          int max_val, int height, int width, short *edges)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!imgs || !edges) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, 1))) return rc;
+    if (n_frames < 1) return CANNY_HIP_ERR_INVALID;
+    GaussTaps probe;
+    if ((rc = make_taps(sigma, probe))) return rc;
+    const size_t frame_px = npx(height, width, 1);
+    // ~64 MB of input per chunk keeps copies long enough to reach PCIe bandwidth
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, (64u << 20) / frame_px));
+    const int n_chunks = (n_frames + chunk - 1) / chunk;
+    const int n_workers = std::min(3, n_chunks);
+    std::vector<int> status(n_workers, CANNY_HIP_OK);
+    std::vector<std::string> errors(n_workers);
+    const int device = ctx->device;
+    auto worker = [&](int wid) {
+        canny_hip_ctx *sub = nullptr;
+        int st = canny_hip_ctx_create(&sub, device);
+        if (st) {
+            status[wid] = st;
+            return;
+        }
+        unsigned char *pin_in = nullptr;
+        short *pin_out = nullptr;
+        void *d_in = nullptr, *d_out = nullptr;
+        const size_t in_bytes = frame_px * chunk, out_bytes = frame_px * chunk * sizeof(short);
+        hipError_t e = hipHostMalloc((void **)&pin_in, in_bytes);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&pin_out, out_bytes);
+        if (e == hipSuccess) e = hipMalloc(&d_in, in_bytes);
+        if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
+        if (e != hipSuccess) {
+            status[wid] = fail(sub, e, "batch staging allocation");
+        } else {
+            for (int c = wid; c < n_chunks && status[wid] == CANNY_HIP_OK; c += n_workers) {
+                int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
+                std::memcpy(pin_in, imgs + (size_t)f0 * frame_px, frame_px * nf);
+                e = hipMemcpyAsync(d_in, pin_in, frame_px * nf, hipMemcpyHostToDevice, sub->stream);
+                if (e != hipSuccess) {
+                    status[wid] = fail(sub, e, "batch H2D");
+                    break;
+                }
+                st = dev_canny(sub, (const unsigned char *)d_in, sigma, min_val, max_val, height, width, nf,
+                               (short *)d_out);
+                if (st) {
+                    status[wid] = st;
+                    break;
+                }
+                e = hipMemcpyAsync(pin_out, d_out, frame_px * nf * sizeof(short), hipMemcpyDeviceToHost, sub->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(sub->stream);
+                if (e != hipSuccess) {
+                    status[wid] = fail(sub, e, "batch D2H");
+                    break;
+                }
+                std::memcpy(edges + (size_t)f0 * frame_px, pin_out, frame_px * nf * sizeof(short));
+            }
+        }
+        if (status[wid] != CANNY_HIP_OK) errors[wid] = sub->last_error;
+        if (pin_in) (void)hipHostFree(pin_in);
+        if (pin_out) (void)hipHostFree(pin_out);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        canny_hip_ctx_destroy(sub);
+    };
+    std::vector<std::thread> threads;
+    for (int i = 1; i < n_workers; i++) threads.emplace_back(worker, i);
+    worker(0);
+    for (auto &t : threads) t.join();
+    for (int i = 0; i < n_workers; i++)
+        if (status[i]) {
+            ctx->last_error = errors[i];
+            return status[i];
+        }
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
+                              int height, int width, short *edges, int n_devices)
+{
+    if (!imgs || !edges || n_frames < 1) return CANNY_HIP_ERR_INVALID;
+    int avail = 0;
+    int rc = canny_hip_device_count(&avail);
+    if (rc) return rc;
+    if (avail < 1) return CANNY_HIP_ERR_NO_DEVICE;
+    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+    n_devices = std::min(n_devices, n_frames);
+    std::vector<int> status(n_devices, CANNY_HIP_OK);
+    const size_t frame_px = npx(height, width, 1);
+    auto worker = [&](int dev) {
+        int b = 0, e = 0;
+        canny_hip_shard_range(n_frames, dev, n_devices, &b, &e);
+        if (e <= b) return;
+        canny_hip_ctx *ctx = nullptr;
+        int st = canny_hip_ctx_create(&ctx, dev);
+        if (!st)
+            st = canny_hip_canny_batch(ctx, imgs + (size_t)b * frame_px, e - b, sigma, min_val, max_val, height, width,
+                                       edges + (size_t)b * frame_px);
+        status[dev] = st;
+        canny_hip_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> threads;
+    for (int d = 1; d < n_devices; d++) threads.emplace_back(worker, d);
+    worker(0);
+    for (auto &t : threads) t.join();
+    for (int s : status)
+        if (s) return s;
+    return CANNY_HIP_OK;
+}
+
+// ---- device-pointer stage functions ---------------------------------------------------------------
+int canny_hip_dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int height, int width,
+                           int n_frames, short *d_result)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_img || !d_result) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    return dev_gaussian(ctx, d_img, sigma, height, width, n_frames, d_result);
+}
+
+int canny_hip_dev_xy_gradient(canny_hip_ctx *ctx, const short *d_img, int height, int width, int n_frames,
+                              short *d_grad_x, short *d_grad_y)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_img || !d_grad_x || !d_grad_y) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    if (height < 2 || width < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    StageTimer tm(ctx, CANNY_HIP_STAGE_XY_GRADIENT);
+    HIP_TRY(ctx, launch_xy_gradient(d_img, d_grad_x, d_grad_y, height, width, n_frames, ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_dev_sobel(canny_hip_ctx *ctx, const short *d_img, int height, int width, int n_frames, short *d_magnitude,
+                        short *d_angle)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_img || !d_magnitude || !d_angle) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    if (height < 2 || width < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL);
+    HIP_TRY(ctx, launch_sobel(d_img, d_magnitude, d_angle, height, width, n_frames, ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_dev_nms(canny_hip_ctx *ctx, const short *d_magnitude, const short *d_angle, int height, int width,
+                      int n_frames, short *d_result)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_magnitude || !d_angle || !d_result) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    StageTimer tm(ctx, CANNY_HIP_STAGE_NMS);
+    HIP_TRY(ctx, launch_nms(d_magnitude, d_angle, d_result, height, width, n_frames, ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int height, int width, int n_frames,
+                            short *d_nms)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_smoothed || !d_nms) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    if (height < 2 || width < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+    HIP_TRY(ctx, launch_sobel_nms(d_smoothed, d_nms, height, width, n_frames, /*domain8=*/true, ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_dev_hysteresis(canny_hip_ctx *ctx, short *d_edge_candidates, int height, int width, int n_frames,
+                             int min_val, int max_val)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_edge_candidates) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    return dev_hysteresis(ctx, d_edge_candidates, height, width, n_frames, min_val, max_val);
+}
+
+int canny_hip_dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
+                        int height, int width, int n_frames, short *d_edges)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_img || !d_edges) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    return dev_canny(ctx, d_img, sigma, min_val, max_val, height, width, n_frames, d_edges);
+}
+
+// ---- profiling --------------------------------------------------------------------------------------
+int canny_hip_profile_enable(canny_hip_ctx *ctx, int on)
+{
+    if (!ctx) return CANNY_HIP_ERR_INVALID;
+    ctx->prof = on != 0;
+    return CANNY_HIP_OK;
+}
+
+static int profile_collect(canny_hip_ctx *ctx)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < CANNY_HIP_STAGE_COUNT; s++) {
+        for (auto &e : ctx->pending[s]) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+                ctx->total_ms[s] += ms;
+                ctx->launches[s] += 1;
+            } else {
+                (void)hipGetLastError();
+            }
+            ctx->pool.push_back(e);
+        }
+        ctx->pending[s].clear();
+    }
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_profile_reset(canny_hip_ctx *ctx)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if ((rc = profile_collect(ctx))) return rc;
+    for (int s = 0; s < CANNY_HIP_STAGE_COUNT; s++) {
+        ctx->total_ms[s] = 0.0;
+        ctx->launches[s] = 0;
+    }
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_profile_get(canny_hip_ctx *ctx, int stage, double *total_ms, long *launches)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (stage < 0 || stage >= CANNY_HIP_STAGE_COUNT || !total_ms || !launches) return CANNY_HIP_ERR_INVALID;
+    if ((rc = profile_collect(ctx))) return rc;
+    *total_ms = ctx->total_ms[stage];
+    *launches = ctx->launches[stage];
+    return CANNY_HIP_OK;
+}
+
+// ---- self-test ----------------------------------------------------------------------------------------
+int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes, unsigned char *bins)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!magnitudes || !bins || lim < 0 || lim > 1020) return CANNY_HIP_ERR_INVALID;
+    size_t total = (size_t)(2 * lim + 1) * (2 * lim + 1);
+    HIP_TRY(ctx, ctx->io[0].ensure(total * 2));
+    HIP_TRY(ctx, ctx->io[1].ensure(total));
+    HIP_TRY(ctx, launch_selftest_mag_angle(lim, (int16_t *)ctx->io[0].p, (uint8_t *)ctx->io[1].p, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(magnitudes, ctx->io[0].p, total * 2, hipMemcpyDeviceToHost, ctx->stream));
+    return d2h_sync(ctx, bins, ctx->io[1].p, total);
+}
+
+} // extern "C"

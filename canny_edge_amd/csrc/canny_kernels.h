@@ -1,0 +1,81 @@
+// canny_kernels.h -- launchers for the gfx950 Canny kernels (internal; the public boundary is
+// include/canny_hip.h).  All launchers are asynchronous on `stream` and return the launch status.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace canny {
+
+constexpr int kMaxCenter = 64;                 // Gaussian half-window (window <= 129)
+constexpr int kMaxWindow = 2 * kMaxCenter + 1;
+constexpr int kTile = 64;                      // hysteresis bit-plane tile: 64 rows x 64 columns
+
+// Gaussian taps exactly as the reference computes them on the host (src/utils.cpp:77-95); passed
+// to kernels by value so they live in scalar registers / the kernarg segment.
+struct GaussTaps {
+    int center;
+    float tap[kMaxWindow];
+};
+
+// Geometry of the hysteresis bit-planes: per frame tiles_y x tiles_x tiles, each 64 words (one
+// 64-bit word = 64 consecutive pixels of one row), stored tile-major so that one wave reads a
+// whole tile with one coalesced 512-byte load.
+struct HystGeom {
+    int height, width, n_frames;
+    int tiles_x, tiles_y;
+    __host__ __device__ size_t words() const { return (size_t)n_frames * tiles_x * tiles_y * kTile; }
+    __host__ __device__ int tiles() const { return n_frames * tiles_x * tiles_y; }
+};
+inline HystGeom make_hyst_geom(int height, int width, int n_frames)
+{
+    HystGeom g;
+    g.height = height;
+    g.width = width;
+    g.n_frames = n_frames;
+    g.tiles_x = (width + kTile - 1) / kTile;
+    g.tiles_y = (height + kTile - 1) / kTile;
+    return g;
+}
+
+// ---- Gaussian (src/utils.cpp:26-68) ---------------------------------------------------------
+// General two-pass path: any window up to kMaxWindow; tmp holds n_frames*H*W floats.
+hipError_t launch_gaussian_generic(const uint8_t *img, float *tmp, int16_t *out, int height, int width,
+                                   int n_frames, const GaussTaps &taps, hipStream_t stream);
+// Wave-marching path for center <= 8 (window <= 17): row pass + LDS column ring in one kernel.
+bool gaussian_march_supported(int center, int height, int width);
+hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, int width, int n_frames,
+                                 const GaussTaps &taps, hipStream_t stream);
+
+// ---- Sobel / NMS (src/utils.cpp:106-308) ----------------------------------------------------
+hipError_t launch_xy_gradient(const int16_t *img, int16_t *gx, int16_t *gy, int height, int width, int n_frames,
+                              hipStream_t stream);
+hipError_t launch_sobel(const int16_t *img, int16_t *mag, int16_t *angle, int height, int width, int n_frames,
+                        hipStream_t stream);
+hipError_t launch_nms(const int16_t *mag, const int16_t *angle, int16_t *out, int height, int width, int n_frames,
+                      hipStream_t stream);
+// Fused Sobel+NMS.  domain8 = smoothed plane known to lie in [0,255] (float sqrt + 24-bit products);
+// otherwise the general path (double sqrt, 64-bit products).
+hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
+                            bool domain8, hipStream_t stream);
+
+// ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
+hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,
+                                int max_val, unsigned *domain_flag, hipStream_t stream);
+// One propagation sweep (`iter` = 0,1,2,...).  stamp has g.tiles() entries; last_change is one word
+// that must be zero before iteration 0.
+hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *stamp, unsigned *last_change,
+                                 int iter, const HystGeom &g, hipStream_t stream);
+hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const HystGeom &g, int edge_value,
+                                hipStream_t stream);
+// findEdgePixels (single frame): seed = {start}, connectable = cand >= min_val && !visited.
+hipError_t launch_fep_classify(const int16_t *cand, const uint8_t *visited, uint64_t *strong, uint64_t *conn,
+                               const HystGeom &g, int start, int min_val, hipStream_t stream);
+hipError_t launch_fep_finalize(int16_t *cand, uint8_t *visited, const uint64_t *strong, const HystGeom &g, int start,
+                               int min_val, hipStream_t stream);
+
+// ---- self-test ------------------------------------------------------------------------------
+hipError_t launch_selftest_mag_angle(int lim, int16_t *mags, uint8_t *bins, hipStream_t stream);
+
+} // namespace canny

@@ -1,0 +1,642 @@
+// canny_kernels.hip -- hand-written HIP kernels for the Canny hot path on MI355X (gfx950, wave64).
+//
+// Bit-exactness rules that shape this file:
+//   * The Gaussian is a chain of separately rounded f32 multiplies and adds followed by an IEEE
+//     divide and a truncating cast (reference src/utils.cpp:37-64).  Everything uses __fmul_rn /
+//     __fadd_rn / __fdiv_rn and the file is built with -ffp-contract=off: an FMA would change pixels.
+//   * Magnitude is floor(sqrt(gx^2+gy^2)) and the angle bin is decided with integers only; both
+//     device rules are proven equal to the reference's libm expressions over the whole reachable
+//     domain (tests/test_oracle_golden.py on the CPU, canny_hip_selftest_mag_angle on the GPU).
+//   * Three different border conventions (H4 in SURVEY.md): Gaussian = truncate + renormalise,
+//     Sobel = clamp in-axis + drop off-axis, NMS / hysteresis = skip.
+#include "canny_kernels.h"
+
+namespace canny {
+
+// ================================================================================================
+// Small device helpers
+// ================================================================================================
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_up(lo, 1);
+    hi = __shfl_up(hi, 1);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_down(lo, 1);
+    hi = __shfl_down(hi, 1);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t lane_u64(uint64_t v, int src_lane)
+{
+    unsigned lo = __shfl((unsigned)v, src_lane), hi = __shfl((unsigned)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- gradient -> magnitude / angle bin --------------------------------------------------------
+// General domain: gx, gy are any values a short can hold (reference src/utils.cpp:212-231).
+__device__ __forceinline__ int magnitude_general(int gx, int gy)
+{
+    long long n = (long long)gx * gx + (long long)gy * gy;
+    return (int)(int16_t)(int)sqrt((double)n); // f64 sqrt is correctly rounded, like the host's
+}
+// Exact-math binning with A=gx^2, B=gy^2, P=gx*gy:
+//   bin 0  iff 2|P| <= A-B  (|gy| <= |gx| tan 22.5deg; equality only at gx=gy=0)
+//   bin 90 iff 2|P| <  B-A  (|gy| >  |gx| tan 67.5deg)
+//   else 45 when gx,gy have the same sign, 135 otherwise.
+__device__ __forceinline__ int angle_bin_general(int gx, int gy)
+{
+    long long A = (long long)gx * gx, B = (long long)gy * gy, P = (long long)gx * gy;
+    long long twoP = 2 * (P < 0 ? -P : P);
+    if (twoP <= A - B) return 0;
+    if (twoP < B - A) return 90;
+    return P > 0 ? 45 : 135;
+}
+// 8-bit domain: |gx|,|gy| <= 1020 so every product fits 24-bit multipliers and f32 is exact.
+// v_sqrt_f32 is a 1-ulp approximation; trunc(sqrt(n + 0.5)) is still exactly floor(sqrt(n)) for
+// n <= 2*1020^2 (margin 1.42 ulp, proven in tests/test_oracle_golden.py).
+__device__ __forceinline__ int magnitude_d8(int gx, int gy)
+{
+    int n = __mul24(gx, gx) + __mul24(gy, gy);
+    return (int)__builtin_amdgcn_sqrtf((float)n + 0.5f);
+}
+__device__ __forceinline__ int angle_bin_d8(int gx, int gy)
+{
+    int A = __mul24(gx, gx), B = __mul24(gy, gy), P = __mul24(gx, gy);
+    int twoP = 2 * (P < 0 ? -P : P);
+    int D = A - B;
+    return (twoP <= D) ? 0 : ((twoP < -D) ? 90 : (P > 0 ? 45 : 135));
+}
+
+// Sobel derivatives of pixel (r,c) of one frame read straight from global memory.
+//   gx: columns clamped to the image, rows outside the image dropped   (src/utils.cpp:114-149)
+//   gy: rows clamped to the image, columns outside the image dropped   (src/utils.cpp:155-186)
+// Both are stored through short by the reference, hence the int16 wrap.
+__device__ __forceinline__ void sobel_at(const int16_t *__restrict__ f, int H, int W, int r, int c, int &gx, int &gy)
+{
+    int cl = c > 0 ? c - 1 : 0, cr = c < W - 1 ? c + 1 : W - 1;
+    int ru = r > 0 ? r - 1 : 0, rd = r < H - 1 ? r + 1 : H - 1;
+    const int16_t *row = f + (size_t)r * W;
+    const int16_t *up = f + (size_t)ru * W;
+    const int16_t *dn = f + (size_t)rd * W;
+    int v = 2 * row[cr] - 2 * row[cl];
+    if (r < H - 1) v += dn[cr] - dn[cl];
+    if (r > 0) v += up[cr] - up[cl];
+    int u = 2 * dn[c] - 2 * up[c];
+    if (c < W - 1) u += dn[c + 1] - up[c + 1];
+    if (c > 0) u += dn[c - 1] - up[c - 1];
+    gx = (int16_t)v;
+    gy = (int16_t)u;
+}
+
+// ================================================================================================
+// Gaussian, general two-pass path (any window <= 129).  One thread per pixel, taps visited in
+// ascending order, out-of-image taps skipped in both the sum and the weight.
+// ================================================================================================
+__global__ __launch_bounds__(256) void gauss_rows_generic_kernel(const uint8_t *__restrict__ img,
+                                                                 float *__restrict__ tmp, int W, size_t total,
+                                                                 GaussTaps t)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % (size_t)W);
+        const uint8_t *row = img + (i - c);
+        float acc = 0.0f, wsum = 0.0f;
+        for (int k = -t.center; k <= t.center; k++) {
+            int cc = c + k;
+            if (cc >= 0 && cc < W) {
+                float w = t.tap[t.center + k];
+                acc = __fadd_rn(acc, __fmul_rn((float)row[cc], w));
+                wsum = __fadd_rn(wsum, w);
+            }
+        }
+        tmp[i] = __fdiv_rn(acc, wsum);
+    }
+}
+
+__global__ __launch_bounds__(256) void gauss_cols_generic_kernel(const float *__restrict__ tmp,
+                                                                 int16_t *__restrict__ out, int H, int W,
+                                                                 size_t total, GaussTaps t)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t rowidx = i / (size_t)W;
+        int r = (int)(rowidx % (size_t)H);
+        float acc = 0.0f, wsum = 0.0f;
+        for (int k = -t.center; k <= t.center; k++) {
+            int rr = r + k;
+            if (rr >= 0 && rr < H) {
+                float w = t.tap[t.center + k];
+                acc = __fadd_rn(acc, __fmul_rn(tmp[i + (ptrdiff_t)k * W], w));
+                wsum = __fadd_rn(wsum, w);
+            }
+        }
+        out[i] = (int16_t)__fdiv_rn(acc, wsum); // float -> short truncates toward zero
+    }
+}
+
+static inline unsigned grid_for(size_t total, int block, unsigned cap = 256u * 32u)
+{
+    size_t g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+hipError_t launch_gaussian_generic(const uint8_t *img, float *tmp, int16_t *out, int height, int width,
+                                   int n_frames, const GaussTaps &taps, hipStream_t stream)
+{
+    size_t total = (size_t)n_frames * height * width;
+    unsigned grid = grid_for(total, 256);
+    hipLaunchKernelGGL(gauss_rows_generic_kernel, dim3(grid), dim3(256), 0, stream, img, tmp, width, total, taps);
+    hipLaunchKernelGGL(gauss_cols_generic_kernel, dim3(grid), dim3(256), 0, stream, tmp, out, height, width, total,
+                       taps);
+    return hipGetLastError();
+}
+
+bool gaussian_march_supported(int, int, int) { return false; }
+hipError_t launch_gaussian_march(const uint8_t *, int16_t *, int, int, int, const GaussTaps &, hipStream_t)
+{
+    return hipErrorNotSupported;
+}
+
+// ================================================================================================
+// Stand-alone Sobel / NMS stage kernels (general domain, one thread per pixel)
+// ================================================================================================
+__global__ __launch_bounds__(256) void xy_gradient_kernel(const int16_t *__restrict__ img, int16_t *__restrict__ gxo,
+                                                          int16_t *__restrict__ gyo, int H, int W, size_t total)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t plane = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t f = i / plane, p = i - f * plane;
+        int r = (int)(p / (size_t)W), c = (int)(p - (size_t)r * W);
+        int gx, gy;
+        sobel_at(img + f * plane, H, W, r, c, gx, gy);
+        gxo[i] = (int16_t)gx;
+        gyo[i] = (int16_t)gy;
+    }
+}
+
+__global__ __launch_bounds__(256) void sobel_kernel(const int16_t *__restrict__ img, int16_t *__restrict__ mag,
+                                                    int16_t *__restrict__ ang, int H, int W, size_t total)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t plane = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t f = i / plane, p = i - f * plane;
+        int r = (int)(p / (size_t)W), c = (int)(p - (size_t)r * W);
+        int gx, gy;
+        sobel_at(img + f * plane, H, W, r, c, gx, gy);
+        mag[i] = (int16_t)magnitude_general(gx, gy);
+        ang[i] = (int16_t)angle_bin_general(gx, gy);
+    }
+}
+
+// Keep mag iff strictly greater than both neighbours along its bin; neighbours outside the image
+// are skipped; unknown angle values give 0 (the reference leaves them unwritten).
+__global__ __launch_bounds__(256) void nms_kernel(const int16_t *__restrict__ mag, const int16_t *__restrict__ ang,
+                                                  int16_t *__restrict__ out, int H, int W, size_t total)
+{
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t plane = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t p = i % plane;
+        int r = (int)(p / (size_t)W), c = (int)(p - (size_t)r * W);
+        bool hl = c > 0, hr = c < W - 1, hu = r > 0, hd = r < H - 1;
+        int m = mag[i];
+        int a = ang[i];
+        bool keep = true;
+        if (a == 0) {
+            if (hl && m <= mag[i - 1]) keep = false;
+            if (hr && m <= mag[i + 1]) keep = false;
+        } else if (a == 45) {
+            if (hr && hu && m <= mag[i + 1 - W]) keep = false;
+            if (hl && hd && m <= mag[i - 1 + W]) keep = false;
+        } else if (a == 90) {
+            if (hu && m <= mag[i - W]) keep = false;
+            if (hd && m <= mag[i + W]) keep = false;
+        } else if (a == 135) {
+            if (hl && hu && m <= mag[i - 1 - W]) keep = false;
+            if (hr && hd && m <= mag[i + 1 + W]) keep = false;
+        } else {
+            keep = false;
+        }
+        out[i] = keep ? (int16_t)m : (int16_t)0;
+    }
+}
+
+hipError_t launch_xy_gradient(const int16_t *img, int16_t *gx, int16_t *gy, int height, int width, int n_frames,
+                              hipStream_t stream)
+{
+    size_t total = (size_t)n_frames * height * width;
+    hipLaunchKernelGGL(xy_gradient_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, img, gx, gy, height,
+                       width, total);
+    return hipGetLastError();
+}
+hipError_t launch_sobel(const int16_t *img, int16_t *mag, int16_t *angle, int height, int width, int n_frames,
+                        hipStream_t stream)
+{
+    size_t total = (size_t)n_frames * height * width;
+    hipLaunchKernelGGL(sobel_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, img, mag, angle, height, width,
+                       total);
+    return hipGetLastError();
+}
+hipError_t launch_nms(const int16_t *mag, const int16_t *angle, int16_t *out, int height, int width, int n_frames,
+                      hipStream_t stream)
+{
+    size_t total = (size_t)n_frames * height * width;
+    hipLaunchKernelGGL(nms_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, mag, angle, out, height, width,
+                       total);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// Fused Sobel + NMS, LDS-tiled.  One 256-thread workgroup per 64x32 output tile:
+//   phase A  stage the smoothed tile with a 2-pixel halo in LDS
+//   phase B  magnitude + bin for the tile with a 1-pixel halo, kept in LDS (never written to HBM)
+//   phase C  directional strict-max test, one coalesced s16 store per pixel
+// HBM traffic = 2 B/px in + 2 B/px out (+ halo re-reads, which the per-XCD L2 absorbs).
+// ================================================================================================
+constexpr int SN_TW = 64, SN_TH = 32;
+
+template <bool D8>
+__global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const int16_t *__restrict__ in,
+                                                             int16_t *__restrict__ out, int H, int W)
+{
+    __shared__ int16_t sm[SN_TH + 4][SN_TW + 4];
+    __shared__ int16_t mg[SN_TH + 2][SN_TW + 2];
+    __shared__ uint8_t bn[SN_TH + 2][SN_TW + 2];
+
+    const size_t plane = (size_t)H * W;
+    const int16_t *f = in + (size_t)blockIdx.z * plane;
+    int16_t *o = out + (size_t)blockIdx.z * plane;
+    const int x0 = blockIdx.x * SN_TW, y0 = blockIdx.y * SN_TH;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < (SN_TH + 4) * (SN_TW + 4); i += 256) {
+        int ly = i / (SN_TW + 4), lx = i - ly * (SN_TW + 4);
+        int r = y0 - 2 + ly, c = x0 - 2 + lx;
+        int16_t v = 0;
+        if (r >= 0 && r < H && c >= 0 && c < W) v = f[(size_t)r * W + c];
+        sm[ly][lx] = v;
+    }
+    __syncthreads();
+
+    for (int i = tid; i < (SN_TH + 2) * (SN_TW + 2); i += 256) {
+        int my = i / (SN_TW + 2), mx = i - my * (SN_TW + 2);
+        int r = y0 - 1 + my, c = x0 - 1 + mx;
+        int m = 0, b = 0;
+        if (r >= 0 && r < H && c >= 0 && c < W) {
+            // LDS coordinates of (r,c) are (my+1, mx+1); clamp/drop decided in image coordinates
+            int ly = my + 1, lx = mx + 1;
+            int lxl = c > 0 ? lx - 1 : lx, lxr = c < W - 1 ? lx + 1 : lx;
+            int lyu = r > 0 ? ly - 1 : ly, lyd = r < H - 1 ? ly + 1 : ly;
+            int v = 2 * sm[ly][lxr] - 2 * sm[ly][lxl];
+            if (r < H - 1) v += sm[ly + 1][lxr] - sm[ly + 1][lxl];
+            if (r > 0) v += sm[ly - 1][lxr] - sm[ly - 1][lxl];
+            int u = 2 * sm[lyd][lx] - 2 * sm[lyu][lx];
+            if (c < W - 1) u += sm[lyd][lx + 1] - sm[lyu][lx + 1];
+            if (c > 0) u += sm[lyd][lx - 1] - sm[lyu][lx - 1];
+            int gx = (int16_t)v, gy = (int16_t)u;
+            if (D8) {
+                m = magnitude_d8(gx, gy);
+                b = angle_bin_d8(gx, gy);
+            } else {
+                m = magnitude_general(gx, gy);
+                b = angle_bin_general(gx, gy);
+            }
+        }
+        mg[my][mx] = (int16_t)m;
+        bn[my][mx] = (uint8_t)b;
+    }
+    __syncthreads();
+
+    const int tx = tid & 63, ty = tid >> 6;
+    const int c = x0 + tx;
+    if (c < W) {
+        const bool hl = c > 0, hr = c < W - 1;
+        for (int yy = ty; yy < SN_TH; yy += 4) {
+            int r = y0 + yy;
+            if (r >= H) break;
+            const bool hu = r > 0, hd = r < H - 1;
+            int my = yy + 1, mx = tx + 1;
+            int m = mg[my][mx];
+            int b = bn[my][mx];
+            bool keep = true;
+            if (b == 0) {
+                if (hl && m <= mg[my][mx - 1]) keep = false;
+                if (hr && m <= mg[my][mx + 1]) keep = false;
+            } else if (b == 45) {
+                if (hr && hu && m <= mg[my - 1][mx + 1]) keep = false;
+                if (hl && hd && m <= mg[my + 1][mx - 1]) keep = false;
+            } else if (b == 90) {
+                if (hu && m <= mg[my - 1][mx]) keep = false;
+                if (hd && m <= mg[my + 1][mx]) keep = false;
+            } else {
+                if (hl && hu && m <= mg[my - 1][mx - 1]) keep = false;
+                if (hr && hd && m <= mg[my + 1][mx + 1]) keep = false;
+            }
+            o[(size_t)r * W + c] = keep ? (int16_t)m : (int16_t)0;
+        }
+    }
+}
+
+hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames, bool domain8,
+                            hipStream_t stream)
+{
+    dim3 grid((width + SN_TW - 1) / SN_TW, (height + SN_TH - 1) / SN_TH, n_frames);
+    if (domain8)
+        hipLaunchKernelGGL(sobel_nms_tile_kernel<true>, grid, dim3(256), 0, stream, smoothed, out, height, width);
+    else
+        hipLaunchKernelGGL(sobel_nms_tile_kernel<false>, grid, dim3(256), 0, stream, smoothed, out, height, width);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// Hysteresis on bit-planes.
+//   classify : one wave per 64-pixel word; __ballot turns the two threshold tests into the
+//              `connectable` (v >= min) and `strong` (connectable && v >= max) bit-planes.
+//   propagate: one wave per 64x64 tile, lane = row.  Bit-parallel 8-neighbour dilation plus a
+//              Kogge-Stone fill along each row, repeated until the tile is stable (wave ballot).
+//              Tiles whose border changed stamp their neighbours for the next sweep.
+//   finalize : reached -> EDGE (255), everything else -> 0.
+// The fixed point ("connectable pixels reachable from a strong pixel") is order independent, so it
+// equals the reference's FIFO flood (src/utils.cpp:322-427) as long as the one missing directed
+// edge (1,0)->(0,1) (src/utils.cpp:378,399: `current - width > 0`) is honoured.
+// ================================================================================================
+__device__ __forceinline__ size_t word_index(const HystGeom &g, int f, int y, int wx)
+{
+    return ((((size_t)f * g.tiles_y + (y >> 6)) * g.tiles_x + wx) << 6) + (y & 63);
+}
+
+__global__ __launch_bounds__(256) void hyst_classify_kernel(const int16_t *__restrict__ cand,
+                                                            uint64_t *__restrict__ strong,
+                                                            uint64_t *__restrict__ conn, HystGeom g, int lo, int hi,
+                                                            unsigned *domain_flag)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t rows_padded = (size_t)g.tiles_y * kTile;
+    const size_t n_words = (size_t)g.n_frames * rows_padded * g.tiles_x;
+    const size_t wave_stride = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t wv = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < n_words; wv += wave_stride) {
+        int wx = (int)(wv % (size_t)g.tiles_x);
+        size_t t = wv / (size_t)g.tiles_x;
+        int y = (int)(t % rows_padded);
+        int f = (int)(t / rows_padded);
+        int x = wx * kTile + lane;
+        bool inside = (y < g.height) && (x < g.width);
+        int v = 0;
+        if (inside) v = cand[((size_t)f * g.height + y) * g.width + x];
+        bool c = inside && v >= lo;
+        bool s = c && v >= hi;
+        if (inside && lo <= 0 && v < lo) atomicOr(domain_flag, 1u);
+        uint64_t mc = __ballot(c), ms = __ballot(s);
+        if (lane == 0) {
+            size_t idx = word_index(g, f, y, wx);
+            conn[idx] = mc;
+            strong[idx] = ms;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restrict__ strong,
+                                                             const uint64_t *__restrict__ conn,
+                                                             unsigned *__restrict__ stamp,
+                                                             unsigned *__restrict__ last_change, int iter, HystGeom g)
+{
+    // Nothing was scheduled for this sweep: the whole grid drains immediately.
+    if (iter > 0 && __hip_atomic_load(last_change, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)iter) return;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= g.tiles()) return;
+    if (iter > 0 && stamp[t] != (unsigned)iter) return;
+
+    const int tpf = g.tiles_x * g.tiles_y;
+    const int tt = t % tpf;
+    const int ty = tt / g.tiles_x, tx = tt - ty * g.tiles_x;
+    const bool hasU = ty > 0, hasD = ty < g.tiles_y - 1, hasL = tx > 0, hasR = tx < g.tiles_x - 1;
+    const size_t base = (size_t)t * kTile;
+    const size_t rowstep = (size_t)g.tiles_x * kTile; // words between vertically adjacent tiles
+
+    const uint64_t c = conn[base + lane];
+    const uint64_t s0 = strong[base + lane];
+    // halo from the eight neighbouring tiles (read once per sweep; a change made there during
+    // this sweep re-stamps us for the next one)
+    const uint64_t su = hasU ? strong[base - rowstep + 63] : 0; // bottom row of the tile above
+    const uint64_t sd = hasD ? strong[base + rowstep] : 0;      // top row of the tile below
+    unsigned lb = hasL ? (unsigned)(strong[base - kTile + lane] >> 63) : 0u; // column 63 of the left tile
+    unsigned rb = hasR ? (unsigned)(strong[base + kTile + lane] & 1u) : 0u;  // column 0 of the right tile
+    const unsigned ul = (hasU && hasL) ? (unsigned)(strong[base - rowstep - kTile + 63] >> 63) : 0u;
+    const unsigned ur = (hasU && hasR) ? (unsigned)(strong[base - rowstep + kTile + 63] & 1u) : 0u;
+    const unsigned dl = (hasD && hasL) ? (unsigned)(strong[base + rowstep - kTile] >> 63) : 0u;
+    const unsigned dr = (hasD && hasR) ? (unsigned)(strong[base + rowstep + kTile] & 1u) : 0u;
+    unsigned lb_up = __shfl_up(lb, 1), lb_dn = __shfl_down(lb, 1);
+    unsigned rb_up = __shfl_up(rb, 1), rb_dn = __shfl_down(rb, 1);
+    if (lane == 0) { lb_up = ul; rb_up = ur; }
+    if (lane == 63) { lb_dn = dl; rb_dn = dr; }
+    const uint64_t in_left = (uint64_t)(lb | lb_up | lb_dn);         // enters at bit 0
+    const uint64_t in_right = (uint64_t)(rb | rb_up | rb_dn) << 63;  // enters at bit 63
+    // image row 0, tile column 0: pixel (0,1) must not pull from pixel (1,0)
+    const bool quirk = (ty == 0 && tx == 0 && lane == 0);
+
+    uint64_t s = s0;
+    for (;;) {
+        uint64_t up = shfl_up_u64(s), dn = shfl_down_u64(s);
+        if (lane == 0) up = su;
+        if (lane == 63) dn = sd;
+        uint64_t d = up | s | dn;
+        uint64_t d_from_left = quirk ? (up | s | (dn & ~1ull)) : d; // what column c may pull from column c-1
+        uint64_t nb = d | (d_from_left << 1) | (d >> 1) | in_left | in_right;
+        uint64_t gsel = s | (c & nb);
+        // flood along the row through runs of connectable pixels (Kogge-Stone, both directions)
+        uint64_t p = c;
+        gsel |= p & (gsel << 1);  p &= p << 1;
+        gsel |= p & (gsel << 2);  p &= p << 2;
+        gsel |= p & (gsel << 4);  p &= p << 4;
+        gsel |= p & (gsel << 8);  p &= p << 8;
+        gsel |= p & (gsel << 16); p &= p << 16;
+        gsel |= p & (gsel << 32);
+        p = c;
+        gsel |= p & (gsel >> 1);  p &= p >> 1;
+        gsel |= p & (gsel >> 2);  p &= p >> 2;
+        gsel |= p & (gsel >> 4);  p &= p >> 4;
+        gsel |= p & (gsel >> 8);  p &= p >> 8;
+        gsel |= p & (gsel >> 16); p &= p >> 16;
+        gsel |= p & (gsel >> 32);
+        bool changed = gsel != s;
+        s = gsel;
+        if (!__any(changed)) break;
+    }
+
+    const uint64_t chg = s ^ s0;
+    if (__any(chg != 0)) {
+        strong[base + lane] = s;
+        const uint64_t top64 = lane_u64(chg, 0);  // changes in the tile's first row
+        const uint64_t bot = lane_u64(chg, 63);   // ... and in its last row
+        const bool anyL = __any((chg & 1ull) != 0), anyR = __any((chg >> 63) != 0);
+        if (lane == 0) {
+            const unsigned nxt = (unsigned)iter + 1u;
+            bool marked = false;
+            if (hasU && top64) { stamp[t - g.tiles_x] = nxt; marked = true; }
+            if (hasD && bot) { stamp[t + g.tiles_x] = nxt; marked = true; }
+            if (hasL && anyL) { stamp[t - 1] = nxt; marked = true; }
+            if (hasR && anyR) { stamp[t + 1] = nxt; marked = true; }
+            if (hasU && hasL && (top64 & 1ull)) { stamp[t - g.tiles_x - 1] = nxt; marked = true; }
+            if (hasU && hasR && (top64 >> 63)) { stamp[t - g.tiles_x + 1] = nxt; marked = true; }
+            if (hasD && hasL && (bot & 1ull)) { stamp[t + g.tiles_x - 1] = nxt; marked = true; }
+            if (hasD && hasR && (bot >> 63)) { stamp[t + g.tiles_x + 1] = nxt; marked = true; }
+            if (marked) atomicMax(last_change, nxt);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hyst_finalize_kernel(int16_t *__restrict__ cand,
+                                                            const uint64_t *__restrict__ strong, HystGeom g,
+                                                            int edge_value)
+{
+    const size_t plane = (size_t)g.height * g.width;
+    const size_t total = plane * g.n_frames;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        size_t f = i / plane, p = i - f * plane;
+        int y = (int)(p / (size_t)g.width), x = (int)(p - (size_t)y * g.width);
+        uint64_t w = strong[word_index(g, (int)f, y, x >> 6)];
+        cand[i] = ((w >> (x & 63)) & 1ull) ? (int16_t)edge_value : (int16_t)0;
+    }
+}
+
+// ---- findEdgePixels (one frame) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void fep_classify_kernel(const int16_t *__restrict__ cand,
+                                                           const uint8_t *__restrict__ visited,
+                                                           uint64_t *__restrict__ strong, uint64_t *__restrict__ conn,
+                                                           HystGeom g, int start, int lo)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t rows_padded = (size_t)g.tiles_y * kTile;
+    const size_t n_words = rows_padded * g.tiles_x;
+    const size_t wave_stride = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t wv = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < n_words; wv += wave_stride) {
+        int wx = (int)(wv % (size_t)g.tiles_x);
+        int y = (int)(wv / (size_t)g.tiles_x);
+        int x = wx * kTile + lane;
+        bool inside = (y < g.height) && (x < g.width);
+        bool c = false, s = false;
+        if (inside) {
+            size_t i = (size_t)y * g.width + x;
+            s = ((long long)i == (long long)start);
+            c = s || (cand[i] >= lo && !visited[i]);
+        }
+        uint64_t mc = __ballot(c), ms = __ballot(s);
+        if (lane == 0) {
+            size_t idx = word_index(g, 0, y, wx);
+            conn[idx] = mc;
+            strong[idx] = ms;
+        }
+    }
+}
+
+__device__ __forceinline__ bool bit_at(const uint64_t *planeS, const HystGeom &g, int y, int x)
+{
+    if (y < 0 || y >= g.height || x < 0 || x >= g.width) return false;
+    return (planeS[word_index(g, 0, y, x >> 6)] >> (x & 63)) & 1ull;
+}
+
+// Reached pixels become EDGE and visited, except `start`, which the reference enqueues without
+// marking it: it only becomes visited when a reached neighbour pushes it again, which needs the
+// directed edge neighbour->start and EDGE >= min_val.
+__global__ __launch_bounds__(256) void fep_finalize_kernel(int16_t *__restrict__ cand, uint8_t *__restrict__ visited,
+                                                           const uint64_t *__restrict__ strong, HystGeom g, int start,
+                                                           int lo)
+{
+    const size_t total = (size_t)g.height * g.width;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int y = (int)(i / (size_t)g.width), x = (int)(i - (size_t)y * g.width);
+        if (!bit_at(strong, g, y, x)) continue;
+        cand[i] = 255;
+        if ((long long)i != (long long)start) {
+            visited[i] = 1;
+        } else if (255 >= lo) {
+            bool pushed = false;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (!dy && !dx) continue;
+                    int py = y + dy, px = x + dx;
+                    if (!bit_at(strong, g, py, px)) continue;
+                    if (py == 1 && px == 0 && y == 0 && x == 1) continue; // (1,0) never pushes (0,1)
+                    pushed = true;
+                }
+            if (pushed) visited[i] = 1;
+        }
+    }
+}
+
+hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,
+                                int max_val, unsigned *domain_flag, hipStream_t stream)
+{
+    size_t n_words = (size_t)g.n_frames * g.tiles_y * kTile * g.tiles_x;
+    hipLaunchKernelGGL(hyst_classify_kernel, dim3(grid_for(n_words * 64, 256)), dim3(256), 0, stream, cand, strong,
+                       conn, g, min_val, max_val, domain_flag);
+    return hipGetLastError();
+}
+hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *stamp, unsigned *last_change,
+                                 int iter, const HystGeom &g, hipStream_t stream)
+{
+    unsigned blocks = (unsigned)((g.tiles() + 3) / 4);
+    hipLaunchKernelGGL(hyst_propagate_kernel, dim3(blocks), dim3(256), 0, stream, strong, conn, stamp, last_change,
+                       iter, g);
+    return hipGetLastError();
+}
+hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const HystGeom &g, int edge_value,
+                                hipStream_t stream)
+{
+    size_t total = (size_t)g.n_frames * g.height * g.width;
+    hipLaunchKernelGGL(hyst_finalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, cand, strong, g,
+                       edge_value);
+    return hipGetLastError();
+}
+hipError_t launch_fep_classify(const int16_t *cand, const uint8_t *visited, uint64_t *strong, uint64_t *conn,
+                               const HystGeom &g, int start, int min_val, hipStream_t stream)
+{
+    size_t n_words = (size_t)g.tiles_y * kTile * g.tiles_x;
+    hipLaunchKernelGGL(fep_classify_kernel, dim3(grid_for(n_words * 64, 256)), dim3(256), 0, stream, cand, visited,
+                       strong, conn, g, start, min_val);
+    return hipGetLastError();
+}
+hipError_t launch_fep_finalize(int16_t *cand, uint8_t *visited, const uint64_t *strong, const HystGeom &g, int start,
+                               int min_val, hipStream_t stream)
+{
+    size_t total = (size_t)g.height * g.width;
+    hipLaunchKernelGGL(fep_finalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, cand, visited, strong, g,
+                       start, min_val);
+    return hipGetLastError();
+}
+
+// ================================================================================================
+// Self-test: the device's 8-bit-domain magnitude and angle rules over every (gx,gy) in [-lim,lim]^2
+// ================================================================================================
+__global__ __launch_bounds__(256) void selftest_mag_angle_kernel(int lim, int16_t *__restrict__ mags,
+                                                                 uint8_t *__restrict__ bins)
+{
+    const int side = 2 * lim + 1;
+    const size_t total = (size_t)side * side;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int gy = (int)(i / side) - lim, gx = (int)(i % side) - lim;
+        mags[i] = (int16_t)magnitude_d8(gx, gy);
+        bins[i] = (uint8_t)angle_bin_d8(gx, gy);
+    }
+}
+hipError_t launch_selftest_mag_angle(int lim, int16_t *mags, uint8_t *bins, hipStream_t stream)
+{
+    size_t total = (size_t)(2 * lim + 1) * (2 * lim + 1);
+    hipLaunchKernelGGL(selftest_mag_angle_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, lim, mags, bins);
+    return hipGetLastError();
+}
+
+} // namespace canny

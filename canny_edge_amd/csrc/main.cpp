@@ -1,0 +1,163 @@
+// main.cpp -- the reference's command line (StevenChang5/Canny_Edge src/main.cpp:18-142) without
+// the webcam and the GUI:  ./Main sigma minVal maxVal [-c] [-s] [-i in.pgm] [-o dir] [-n WxH]
+//
+// Kept from the reference: the three positionals may appear anywhere relative to the flags
+// (src/main.cpp:29-46); exactly three are required, otherwise the usage text is printed and the
+// program exits with status 0 (:48-56); maxVal must exceed minVal and both must lie in [0,255]
+// (:63-76), again exiting 0 with the reference's messages; -s shows the steps, -c selects the GPU
+// entry point (cuda_canny) instead of canny().  In this build both run on the MI355X.
+// Replaced: VideoCapture(0) 640x480 (:78-115) -> a binary PGM given with -i, or a synthetic frame
+// of the webcam's size (-n overrides the size); imshow -> PGM files in the -o directory.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "utils.h"
+#include "cuda.h"
+
+#define WIDTH 640
+#define HEIGHT 480
+
+using namespace std;
+
+static bool read_pgm(const string &path, vector<unsigned char> &px, int &height, int &width)
+{
+    ifstream f(path, ios::binary);
+    if (!f) return false;
+    string magic;
+    f >> magic;
+    if (magic != "P5") return false;
+    auto next_int = [&](int &v) {
+        f >> ws;
+        while (f.peek() == '#') {
+            string line;
+            getline(f, line);
+            f >> ws;
+        }
+        return (bool)(f >> v);
+    };
+    int maxv = 0;
+    if (!next_int(width) || !next_int(height) || !next_int(maxv)) return false;
+    if (width < 1 || height < 1 || maxv < 1 || maxv > 255) return false;
+    f.get(); // single whitespace after maxval
+    px.resize((size_t)width * height);
+    f.read((char *)px.data(), (streamsize)px.size());
+    return (size_t)f.gcount() == px.size();
+}
+
+// Deterministic test card: gray background, filled rectangles, a little noise (xorshift).
+static void synthetic_frame(vector<unsigned char> &px, int height, int width)
+{
+    px.assign((size_t)width * height, 30);
+    unsigned s = 42u;
+    auto rnd = [&]() {
+        s ^= s << 13;
+        s ^= s >> 17;
+        s ^= s << 5;
+        return s;
+    };
+    int rects = (int)(((long long)width * height) / 8000 + 4);
+    for (int i = 0; i < rects; i++) {
+        int w = 8 + (int)(rnd() % (unsigned)(width / 6 > 8 ? width / 6 - 7 : 1));
+        int h = 8 + (int)(rnd() % (unsigned)(height / 6 > 8 ? height / 6 - 7 : 1));
+        int x0 = (int)(rnd() % (unsigned)width), y0 = (int)(rnd() % (unsigned)height);
+        unsigned char lv = (unsigned char)(rnd() & 255u);
+        for (int y = y0; y < y0 + h && y < height; y++)
+            for (int x = x0; x < x0 + w && x < width; x++) px[(size_t)y * width + x] = lv;
+    }
+    for (auto &p : px) {
+        int v = (int)p + (int)(rnd() % 17u) - 8;
+        p = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+int main(int argc, char *argv[])
+{
+    float sigma;
+    int minVal;
+    int maxVal;
+    bool use_gpu_entry = false;
+    bool show_steps = false;
+    string input, outdir;
+    int width = WIDTH, height = HEIGHT;
+    vector<string> values;
+
+    for (int i = 1; i < argc; i++) {
+        string arg = argv[i];
+        if (arg == "-c") {
+            use_gpu_entry = true;
+        } else if (arg == "-s") {
+            show_steps = true;
+        } else if (arg == "-i" && i + 1 < argc) {
+            input = argv[++i];
+        } else if (arg == "-o" && i + 1 < argc) {
+            outdir = argv[++i];
+        } else if (arg == "-n" && i + 1 < argc) {
+            if (sscanf(argv[++i], "%dx%d", &width, &height) != 2 || width < 2 || height < 2) {
+                fprintf(stderr, "ERROR: -n expects WIDTHxHEIGHT\n");
+                exit(0);
+            }
+        } else {
+            values.push_back(arg);
+        }
+    }
+
+    if (values.size() != 3) {
+        fprintf(stderr, "USAGE: %s sigma minVal maxVal\n", argv[0]);
+        fprintf(stderr, "   sigma: Standard deviation used for the gaussian blurring kernel\n");
+        fprintf(stderr, "   minVal: The minimum threshold value used for hysteresis\n");
+        fprintf(stderr, "           Must be in the range of [0,255]\n");
+        fprintf(stderr, "   maxVal: The maximum threshold value used for hysteresis\n");
+        fprintf(stderr, "           Must be in the range of [0,255]\n");
+        fprintf(stderr, "   -c: use the GPU entry point (cuda_canny)   -s: write every step\n");
+        fprintf(stderr, "   -i in.pgm: input frame (binary PGM)   -n WxH: synthetic frame size   -o dir: output dir\n");
+        exit(0);
+    }
+
+    try {
+        sigma = stof(values[0]);
+        minVal = stoi(values[1]);
+        maxVal = stoi(values[2]);
+    } catch (const exception &) {
+        fprintf(stderr, "ERROR: sigma, minVal and maxVal must be numbers\n");
+        exit(0);
+    }
+
+    if (maxVal <= minVal) {
+        fprintf(stderr, "ERROR: minVal must be less than maxVal\n");
+        exit(0);
+    }
+    if (minVal < 0 or minVal > 255) {
+        fprintf(stderr, "ERROR: minVal must be in the range of [0,255]");
+        exit(0);
+    }
+    if (maxVal < 0 or maxVal > 255) {
+        fprintf(stderr, "ERROR: maxVal must be in the range of [0,255]");
+        exit(0);
+    }
+
+    vector<unsigned char> frame;
+    if (!input.empty()) {
+        if (!read_pgm(input, frame, height, width)) {
+            cout << "ERROR: Failed to open " << input << endl;
+            return -1;
+        }
+    } else {
+        synthetic_frame(frame, height, width);
+    }
+    if (!outdir.empty()) setenv("CANNY_OUTPUT_DIR", outdir.c_str(), 1);
+
+    try {
+        if (use_gpu_entry)
+            cuda_canny(frame.data(), sigma, minVal, maxVal, height, width, show_steps);
+        else
+            canny(frame.data(), sigma, minVal, maxVal, height, width, show_steps);
+    } catch (const exception &e) {
+        fprintf(stderr, "ERROR: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

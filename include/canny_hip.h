@@ -1,0 +1,171 @@
+/*
+ * canny_hip.h -- C ABI of libcanny_hip.so: the MI355X (gfx950) Canny hot path.
+ *
+ * This is the drop-in boundary for StevenChang5/Canny_Edge's stage functions.  Every entry point
+ * takes plain pointers and sizes (no C++ references, no torch types) so that it can be bound from
+ * C, C++ (include/utils.h shims), Python ctypes (canny_edge_amd/capi.py) or any other FFI.
+ *
+ * Reference interface each function replaces (paths relative to the reference checkout):
+ *
+ *   canny_hip_gaussian_kernel      createGaussianKernel     src/utils.h:10   src/utils.cpp:77-95
+ *   canny_hip_gaussian             gaussian                 src/utils.h:8    src/utils.cpp:26-68
+ *                                  cuda_gaussian            src/cuda.h:4     src/cuda.cu:75-102
+ *   canny_hip_xy_gradient          calculateXYGradient      src/utils.h:12   src/utils.cpp:106-187
+ *   canny_hip_sobel                sobelOperator            src/utils.h:14   src/utils.cpp:201-236
+ *                                  cuda_sobel               src/cuda.h:6     src/cuda.cu:220-246
+ *   canny_hip_nms                  nonmaximalSuppression    src/utils.h:16   src/utils.cpp:248-308
+ *                                  cuda_nonmaixmal_suppression src/cuda.h:8  src/cuda.cu:366-390
+ *   canny_hip_hysteresis           hysteresis               src/utils.h:18   src/utils.cpp:322-342
+ *   canny_hip_find_edge_pixels     findEdgePixels           src/utils.h:20   src/utils.cpp:360-427
+ *   canny_hip_canny                canny / cuda_canny       src/utils.h:22   src/utils.cpp:429-492
+ *                                                           src/cuda.h:10    src/cuda.cu:392-450
+ *
+ * Conventions (same as the reference): images are dense row-major, pixel (r,c) at r*width+c;
+ * argument order is (..., height, width, ...); `short` planes are int16; thresholds are ints.
+ * Unlike the reference's void functions every call returns a status (0 = CANNY_HIP_OK).
+ * Results are bit-identical to the reference's CPU path (src/utils.cpp) on the documented domain.
+ *
+ * Numeric domain:
+ *   - gaussian: any u8 image, sigma finite and > 0, window 1+2*ceil(3*sigma) <= CANNY_HIP_MAX_WINDOW.
+ *   - xy_gradient / sobel / sobel_nms: height >= 2 and width >= 2 (the reference reads out of bounds
+ *     below that).  Gradients are stored through short exactly like the reference.  Angle bins are
+ *     computed with an exact integer rule that is proven equal to the reference's
+ *     atan2/float expression for every |gx|,|gy| <= 1020, i.e. for every smoothed plane in [0,255]
+ *     (everything gaussian() can produce); outside that range a gradient lying within float rounding
+ *     of a bin boundary may be binned differently from the reference.
+ *   - hysteresis: if min_val <= 0 the reference's result depends on its scan order whenever a
+ *     candidate is below min_val; that case returns CANNY_HIP_ERR_DOMAIN.
+ *
+ * Threading: a context is bound to one device and one stream and must be used by one host thread
+ * at a time; different contexts may be used concurrently (one per GPU / per host thread).
+ */
+#ifndef CANNY_HIP_H
+#define CANNY_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CANNY_HIP_VERSION 100        /* 0.1.0 */
+#define CANNY_HIP_MAX_WINDOW 129     /* largest Gaussian window (sigma <= 21.33) */
+
+typedef struct canny_hip_ctx canny_hip_ctx;
+
+enum canny_hip_status {
+    CANNY_HIP_OK = 0,
+    CANNY_HIP_ERR_INVALID = 1,     /* null pointer, non-positive size, bad sigma ... */
+    CANNY_HIP_ERR_UNSUPPORTED = 2, /* size or window beyond what the kernels support */
+    CANNY_HIP_ERR_NO_DEVICE = 3,   /* no usable HIP device: there is NO CPU fallback */
+    CANNY_HIP_ERR_RUNTIME = 4,     /* HIP runtime failure, see canny_hip_last_error() */
+    CANNY_HIP_ERR_DOMAIN = 5,      /* input outside the documented numeric domain */
+    CANNY_HIP_ERR_NO_CONVERGE = 6  /* hysteresis propagation hit its iteration cap */
+};
+
+/* Stages for the per-stage HIP-event profile (canny_hip_profile_*). */
+enum canny_hip_stage {
+    CANNY_HIP_STAGE_GAUSSIAN = 0,
+    CANNY_HIP_STAGE_SOBEL_NMS = 1,      /* the fused Sobel+NMS pass (roofline-graded kernel) */
+    CANNY_HIP_STAGE_HYST_CLASSIFY = 2,
+    CANNY_HIP_STAGE_HYST_PROPAGATE = 3,
+    CANNY_HIP_STAGE_HYST_FINALIZE = 4,
+    CANNY_HIP_STAGE_SOBEL = 5,
+    CANNY_HIP_STAGE_NMS = 6,
+    CANNY_HIP_STAGE_XY_GRADIENT = 7,
+    CANNY_HIP_STAGE_COUNT = 8
+};
+
+/* ---- library / context ------------------------------------------------------------------- */
+int canny_hip_version(void);
+const char *canny_hip_status_string(int status);
+int canny_hip_device_count(int *count);
+
+/* Creates a context on `device` with its own non-blocking stream. */
+int canny_hip_ctx_create(canny_hip_ctx **ctx, int device);
+void canny_hip_ctx_destroy(canny_hip_ctx *ctx);
+/* Makes the context launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL
+ * restores the context's own stream. */
+int canny_hip_ctx_set_stream(canny_hip_ctx *ctx, void *hip_stream);
+int canny_hip_ctx_device(const canny_hip_ctx *ctx);
+int canny_hip_synchronize(canny_hip_ctx *ctx);
+/* Text of the last HIP runtime error seen by this context ("" if none). */
+const char *canny_hip_last_error(const canny_hip_ctx *ctx);
+/* Number of propagate launches that did work in the last hysteresis call (diagnostic). */
+int canny_hip_last_hysteresis_iterations(const canny_hip_ctx *ctx);
+
+/* ---- device / pinned memory helpers (for hosts without their own HIP allocator) ----------- */
+int canny_hip_malloc(canny_hip_ctx *ctx, void **dev_ptr, size_t bytes);
+int canny_hip_free(canny_hip_ctx *ctx, void *dev_ptr);
+int canny_hip_host_alloc(canny_hip_ctx *ctx, void **host_ptr, size_t bytes); /* pinned */
+int canny_hip_host_free(canny_hip_ctx *ctx, void *host_ptr);
+int canny_hip_memcpy_h2d(canny_hip_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int canny_hip_memcpy_d2h(canny_hip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
+/* ---- stage entry points on HOST buffers (synchronous; one frame) --------------------------- */
+/* createGaussianKernel: host-only.  taps must hold `cap` floats; *window receives 1+2*ceil(3*sigma). */
+int canny_hip_gaussian_kernel(float sigma, float *taps, int cap, int *window);
+int canny_hip_gaussian(canny_hip_ctx *ctx, const unsigned char *img, float sigma, int height, int width,
+                       short *result);
+int canny_hip_xy_gradient(canny_hip_ctx *ctx, const short *img, int height, int width, short *grad_x,
+                          short *grad_y);
+int canny_hip_sobel(canny_hip_ctx *ctx, const short *img, int height, int width, short *magnitude,
+                    short *angle);
+int canny_hip_nms(canny_hip_ctx *ctx, const short *magnitude, const short *angle, int height, int width,
+                  short *result);
+/* In place, like the reference. */
+int canny_hip_hysteresis(canny_hip_ctx *ctx, short *edge_candidates, int height, int width, int min_val,
+                         int max_val);
+/* In place on both arrays; visited is one byte per pixel (C++ bool). */
+int canny_hip_find_edge_pixels(canny_hip_ctx *ctx, short *edge_candidates, unsigned char *visited, int start,
+                               int min_val, int max_val, int height, int width);
+/* Whole pipeline; unlike the reference's canny() the {0,255} edge map is returned in `edges`. */
+int canny_hip_canny(canny_hip_ctx *ctx, const unsigned char *img, float sigma, int min_val, int max_val,
+                    int height, int width, short *edges);
+/* n_frames contiguous frames in, n_frames edge maps out; H2D, kernels and D2H of successive chunks
+ * overlap on separate streams with pinned staging (BASELINE config 3). */
+int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                          int max_val, int height, int width, short *edges);
+/* Shards n_frames by contiguous ranges over n_devices GPUs (devices 0..n_devices-1), one host
+ * thread and one context per GPU, no collective (BASELINE config 5).  n_devices <= 0 = all. */
+int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
+                              int height, int width, short *edges, int n_devices);
+/* Frame range [begin, end) of shard `rank` of `world` (what canny_hip_canny_multi_gpu and bench.py use). */
+int canny_hip_shard_range(int n_frames, int rank, int world, int *begin, int *end);
+
+/* ---- stage entry points on DEVICE buffers (asynchronous on the context's stream) ----------- */
+/* All planes hold n_frames contiguous frames.  Workspace is owned and grown by the context. */
+int canny_hip_dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int height, int width,
+                           int n_frames, short *d_result);
+int canny_hip_dev_xy_gradient(canny_hip_ctx *ctx, const short *d_img, int height, int width, int n_frames,
+                              short *d_grad_x, short *d_grad_y);
+int canny_hip_dev_sobel(canny_hip_ctx *ctx, const short *d_img, int height, int width, int n_frames,
+                        short *d_magnitude, short *d_angle);
+int canny_hip_dev_nms(canny_hip_ctx *ctx, const short *d_magnitude, const short *d_angle, int height, int width,
+                      int n_frames, short *d_result);
+/* Fused Sobel + NMS: smoothed s16 in, suppressed magnitude s16 out; magnitude and angle never reach
+ * HBM (4 algorithmic bytes per pixel).  d_smoothed must lie in [0,255] (gaussian output). */
+int canny_hip_dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int height, int width, int n_frames,
+                            short *d_nms);
+/* In place.  Blocks the host until propagation has converged (it polls a device flag). */
+int canny_hip_dev_hysteresis(canny_hip_ctx *ctx, short *d_edge_candidates, int height, int width, int n_frames,
+                             int min_val, int max_val);
+/* gaussian -> fused sobel+nms -> hysteresis over n_frames resident frames. */
+int canny_hip_dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
+                        int height, int width, int n_frames, short *d_edges);
+
+/* ---- per-stage HIP-event timing (events are recorded on the launch stream) ----------------- */
+int canny_hip_profile_enable(canny_hip_ctx *ctx, int on);
+int canny_hip_profile_reset(canny_hip_ctx *ctx);
+/* Synchronises the stream, then returns accumulated device milliseconds and launch count. */
+int canny_hip_profile_get(canny_hip_ctx *ctx, int stage, double *total_ms, long *launches);
+
+/* ---- self-test hooks used by the GPU test-suite -------------------------------------------- */
+/* Runs the DEVICE magnitude / angle-bin functions over every (gx,gy) in [-lim,lim]^2 and writes
+ * tables indexed [gy+lim][gx+lim] to host memory. */
+int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes, unsigned char *bins);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CANNY_HIP_H */

@@ -1,0 +1,106 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/canny_hip.h declares, refuses to run without a GPU (no CPU fallback), and its host-only
+pieces (Gaussian taps, shard ranges) match the oracle.  No kernel is launched here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from canny_edge_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu() -> bool:
+    return capi.device_count() > 0
+
+
+def test_header_symbols_all_exported():
+    header = open(os.path.join(ROOT, "include", "canny_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(canny_hip_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 35
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    missing = [name for name in declared if not hasattr(lib, name)]
+    assert not missing, f"declared in canny_hip.h but not exported: {missing}"
+    assert sorted(capi.EXPORTS) == declared, "capi.EXPORTS out of sync with the header"
+
+
+def test_version_and_status_strings():
+    L = capi.load()
+    assert L.canny_hip_version() == 100
+    assert capi.status_string(0) == "ok"
+    assert "CPU fallback" in capi.status_string(3)
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _has_gpu():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.CannyHipError) as ei:
+        capi.Context(0)
+    assert ei.value.status == 3  # CANNY_HIP_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("sigma", [0.3, 0.5, 0.8, 1.0, 1.4, 2.0, 2.5, 3.3, 7.0, 21.0])
+def test_host_gaussian_taps_match_oracle_bitwise(sigma):
+    got = capi.createGaussianKernel(sigma)
+    want = oracle.gaussian_kernel(sigma)
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert got.tobytes() == want.tobytes()
+
+
+def test_host_gaussian_taps_reference_vector(ref_vectors):
+    case = ref_vectors["gaussian_kernel"][1]  # tests/utils/test_utils.cpp:21-32
+    got = capi.createGaussianKernel(case["sigma"])
+    assert len(got) == case["window"]
+    eps = float(np.finfo(np.float32).eps)
+    assert all(abs(np.float32(w) - g) < eps for g, w in zip(got, case["expected"]))
+    k2 = capi.createGaussianKernel(2.0)       # tests/utils/test_utils.cpp:34-45
+    assert len(k2) == 13 and all(k2[i] == k2[12 - i] for i in range(7))
+
+
+@pytest.mark.parametrize("sigma", [0.0, -1.0, float("nan"), float("inf"), 30.0])
+def test_host_gaussian_taps_rejects_bad_sigma(sigma):
+    with pytest.raises(capi.CannyHipError):
+        capi.createGaussianKernel(sigma)
+
+
+@pytest.mark.parametrize("n,world", [(8192, 8), (1024, 3), (7, 8), (0, 4), (1, 1), (100, 6)])
+def test_shard_ranges_partition_the_batch(n, world):
+    ranges = [capi.shard_range(n, r, world) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == n
+    for (b0, e0), (b1, e1) in zip(ranges, ranges[1:]):
+        assert e0 == b1 and b0 <= e0 and b1 <= e1
+    sizes = [e - b for b, e in ranges]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_utils_shim_exports_reference_mangled_names():
+    """The C++ drop-in must export exactly the symbols the reference's utils.h / cuda.h produce
+    (SURVEY.md 8b lists the mangled names of src/utils.h:8-22)."""
+    so = os.path.join(ROOT, "canny_edge_amd", "libcanny_utils.so")
+    assert os.path.exists(so)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    for name in ("_Z8gaussianRPhfiiRPs", "_Z20createGaussianKernelRPffPi", "_Z19calculateXYGradientRPsiiS0_S0_",
+                 "_Z13sobelOperatorRPsiiS0_S0_", "_Z21nonmaximalSuppressionRPsS0_iiS0_", "_Z10hysteresisRPsiiii",
+                 "_Z14findEdgePixelsRPsRPbiiiii", "_Z5cannyPhfiiiib"):
+        assert name in syms, name
+    for name in ("cuda_gaussian", "cuda_sobel", "cuda_nonmaixmal_suppression", "cuda_canny"):
+        assert re.search(rf"_Z\d+{name}", syms), name
+
+
+def test_cli_keeps_reference_grammar():
+    """src/main.cpp:29-76: three positionals anywhere among the flags, usage + exit(0) otherwise,
+    max > min, both in [0,255], every failure exits with status 0."""
+    exe = os.path.join(ROOT, "canny_edge_amd", "Main")
+    r = subprocess.run([exe, "1.0", "50"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stderr.startswith("USAGE:")
+    r = subprocess.run([exe, "-s", "1.0", "150", "-c", "50"], capture_output=True, text=True)
+    assert r.returncode == 0 and "minVal must be less than maxVal" in r.stderr
+    r = subprocess.run([exe, "1.0", "-5", "50"], capture_output=True, text=True)
+    assert r.returncode == 0 and "minVal must be in the range of [0,255]" in r.stderr
+    r = subprocess.run([exe, "1.0", "50", "300"], capture_output=True, text=True)
+    assert r.returncode == 0 and "maxVal must be in the range of [0,255]" in r.stderr

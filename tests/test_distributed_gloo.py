@@ -1,0 +1,63 @@
+"""N>1 path on the CPU: two gloo ranks shard a batch with the product's sharding rules, each rank runs
+its shard (here through the oracle, since there is no GPU in the build container), and rank 0 checks
+that the gathered result equals the single-process result and that the timing reduction is a MAX."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from canny_edge_amd import sharding
+from canny_edge_amd.synth import synth_frame
+
+N_FRAMES, H, W = 5, 48, 64
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_q):
+    import oracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert sharding.rank_env() == (rank, world, rank)
+        frames = np.stack([synth_frame(H, W, 100 + i) for i in range(N_FRAMES)])
+        b, e = sharding.shard_range(N_FRAMES, rank, world)
+        mine = np.stack([oracle.canny(f, 1.0, 50, 150) for f in frames[b:e]]) if e > b else \
+            np.empty((0, H, W), np.int16)
+        dist.barrier()
+        slow = sharding.max_over_ranks(1.0 + rank)            # rank 1 pretends to be slower
+        padded = np.zeros((N_FRAMES, H, W), np.int16)
+        padded[b:e] = mine
+        t = torch.from_numpy(padded.astype(np.int32))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)               # disjoint shards: SUM == concatenation
+        if rank == 0:
+            want = np.stack([oracle.canny(f, 1.0, 50, 150) for f in frames])
+            out_q.put((bool(np.array_equal(t.numpy().astype(np.int16), want)), slow, (b, e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_max_timing():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, slow, rng0 = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok, "gathered shards differ from the single-process result"
+    assert slow == 2.0, "timing must be the MAX over ranks"
+    assert rng0 == (0, 3)
+    assert sharding.aggregate_throughput(10, 2, 4.0) == 5.0

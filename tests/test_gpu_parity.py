@@ -1,0 +1,378 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and against
+the reference's own known-answer vectors.  Integer planes must be BIT-EXACT; there is no tolerance
+anywhere in this file (the pipeline has no floating-point output: the float Gaussian intermediate
+is truncated to short inside the kernel, exactly like the reference)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+from canny_edge_amd.synth import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _noise(h, w, seed):
+    return np.random.default_rng(seed).integers(0, 256, size=(h, w), dtype=np.uint8)
+
+
+def _mixed(h, w, seed):
+    """Blocks + gradients + noise: many weak/strong pixels and long connected edges."""
+    img = synth_frame(h, w, seed).astype(np.int16)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = img // 2 + ((xx * 3 + yy * 2) % 128).astype(np.int16)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+SIZES = [(2, 2), (2, 9), (9, 2), (3, 3), (5, 7), (16, 16), (31, 33), (64, 64), (65, 63), (97, 131), (128, 192),
+         (200, 257), (240, 320)]
+
+
+# ---------------------------------------------------------------------------------------------
+# 1. The reference's own vectors replayed through the HIP C-ABI (tests/utils/test_utils.cpp)
+# ---------------------------------------------------------------------------------------------
+def test_ref_gradient_vectors(hip, ref_vectors):
+    for case in ref_vectors["gradient"]:
+        img = np.array(case["img"], np.int16).reshape(case["rows"], case["columns"])
+        gx, gy = hip.calculateXYGradient(img)
+        assert gx.ravel().tolist() == case["gx"], case["name"]
+        assert gy.ravel().tolist() == case["gy"], case["name"]
+
+
+def test_ref_sobel_constant(hip, ref_vectors):
+    case = ref_vectors["sobel"][0]
+    img = np.array(case["img"], np.int16).reshape(3, 3)
+    mag, ang = hip.sobelOperator(img)
+    assert mag.shape == ang.shape == (3, 3) and not mag.any() and not ang.any()
+
+
+def test_ref_angle_vector(ctx, ref_vectors):
+    case = ref_vectors["angle_bins"][0]
+    _, bins = ctx.selftest_mag_angle(8)
+    got = [int(bins[gy + 8, gx + 8]) for gx, gy in zip(case["gx"], case["gy"])]
+    assert got == case["angle"]
+
+
+def test_ref_nms_vectors(hip, ref_vectors):
+    for case in ref_vectors["nms"]:
+        shape = (case["rows"], case["columns"])
+        out = hip.nonmaximalSuppression(np.array(case["grad"], np.int16).reshape(shape),
+                                        np.array(case["angle"], np.int16).reshape(shape))
+        assert out.ravel().tolist() == case["expected"], case["name"]
+
+
+def test_ref_find_edge_pixels_vector(hip, ref_vectors):
+    case = ref_vectors["find_edge_pixels"][0]
+    shape = (case["rows"], case["columns"])
+    out, _ = hip.findEdgePixels(np.array(case["suppress"], np.int16).reshape(shape), np.zeros(shape, np.uint8),
+                                case["start"], case["min"], case["max"])
+    assert out.ravel().tolist() == case["expected"]
+
+
+def test_ref_hysteresis_vector(hip, ref_vectors):
+    case = ref_vectors["hysteresis"][0]
+    shape = (case["rows"], case["columns"])
+    out = hip.hysteresis(np.array(case["suppress"], np.int16).reshape(shape), case["min"], case["max"])
+    assert out.ravel().tolist() == case["expected"]
+
+
+def test_ref_gaussian_fixture(hip, ref_vectors, fixture_image):
+    case = ref_vectors["gaussian_image"][0]
+    out = hip.gaussian(fixture_image, case["sigma"])
+    assert out.shape == (256, 256) and int(out.astype(np.int64).sum()) != 0
+    assert out.min() >= 0 and out.max() <= 255
+
+
+# ---------------------------------------------------------------------------------------------
+# 2. Device arithmetic rules, exhaustively
+# ---------------------------------------------------------------------------------------------
+def test_device_magnitude_and_angle_exhaustive(ctx):
+    """Every gradient a [0,255] plane can produce: |gx|,|gy| <= 1020 (4.16 M pairs)."""
+    mags, bins = ctx.selftest_mag_angle(1020)
+    assert np.array_equal(bins, oracle.angle_table(1020))
+    assert np.array_equal(mags, oracle.magnitude_table(1020))
+
+
+# ---------------------------------------------------------------------------------------------
+# 3. Stage-by-stage parity against the oracle on seeded inputs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sigma", [0.3, 0.5, 1.0, 1.4, 2.0, 2.7, 4.0])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 40), (40, 1), (3, 5), (17, 19), (64, 64), (97, 131), (130, 260)])
+def test_gaussian_parity(ctx, sigma, shape):
+    for seed, gen in ((1, _noise), (2, _mixed)):
+        img = gen(shape[0], shape[1], seed)
+        assert np.array_equal(ctx.gaussian(img, sigma), oracle.gaussian(img, sigma)), (sigma, shape, seed)
+
+
+def test_gaussian_extremes(ctx):
+    for fill in (0, 255):
+        img = np.full((50, 70), fill, np.uint8)
+        assert np.array_equal(ctx.gaussian(img, 1.4), oracle.gaussian(img, 1.4))
+    img = np.zeros((40, 40), np.uint8)
+    img[::2, ::2] = 255
+    for s in (0.5, 1.0, 2.0, 6.5):
+        assert np.array_equal(ctx.gaussian(img, s), oracle.gaussian(img, s))
+
+
+@pytest.mark.parametrize("shape", SIZES)
+def test_gradient_sobel_parity(ctx, shape):
+    h, w = shape
+    sm = oracle.gaussian(_mixed(h, w, 3), 1.0)
+    for plane in (sm, _noise(h, w, 4).astype(np.int16)):
+        gx, gy = ctx.xy_gradient(plane)
+        ogx, ogy = oracle.xy_gradient(plane)
+        assert np.array_equal(gx, ogx) and np.array_equal(gy, ogy)
+        mag, ang = ctx.sobel(plane)
+        omag, oang = oracle.sobel(plane)
+        assert np.array_equal(mag, omag) and np.array_equal(ang, oang)
+
+
+def test_sobel_general_domain_wraps_like_the_reference(ctx):
+    """Arbitrary shorts: gradients wrap through short, magnitude through (short)(int)sqrt."""
+    rng = np.random.default_rng(5)
+    plane = rng.integers(-3000, 3000, size=(33, 47), dtype=np.int16)
+    gx, gy = ctx.xy_gradient(plane)
+    ogx, ogy = oracle.xy_gradient(plane)
+    assert np.array_equal(gx, ogx) and np.array_equal(gy, ogy)
+    mag, _ = ctx.sobel(plane)
+    assert np.array_equal(mag, oracle.sobel(plane)[0])
+
+
+@pytest.mark.parametrize("shape", SIZES + [(1, 1), (1, 9), (9, 1)])
+def test_nms_parity(ctx, shape):
+    h, w = shape
+    rng = np.random.default_rng(6)
+    mag = rng.integers(0, 40, size=(h, w), dtype=np.int16)          # many ties
+    ang = rng.choice(np.array([0, 45, 90, 135], np.int16), size=(h, w))
+    assert np.array_equal(ctx.nms(mag, ang), oracle.nms(mag, ang))
+    mag2 = rng.integers(0, 1443, size=(h, w), dtype=np.int16)
+    assert np.array_equal(ctx.nms(mag2, ang), oracle.nms(mag2, ang))
+
+
+@pytest.mark.parametrize("shape", SIZES)
+def test_fused_sobel_nms_equals_separate_stages(ctx, hip, shape):
+    h, w = shape
+    for seed in (7, 8):
+        sm = oracle.gaussian(_mixed(h, w, seed), 1.0)
+        want = oracle.nms(*oracle.sobel(sm))
+        d_in, d_out = ctx.malloc(sm.nbytes), ctx.malloc(sm.nbytes)
+        try:
+            ctx.h2d(d_in, sm)
+            ctx.dev_sobel_nms(d_in, h, w, 1, d_out)
+            got = np.empty_like(sm)
+            ctx.d2h(got, d_out)
+        finally:
+            ctx.free(d_in)
+            ctx.free(d_out)
+        assert np.array_equal(got, want), (shape, seed)
+
+
+@pytest.mark.parametrize("shape", SIZES + [(1, 1), (1, 70), (70, 1), (63, 129), (129, 65)])
+@pytest.mark.parametrize("lohi", [(50, 150), (1, 2), (10, 10), (0, 1), (100, 300), (200, 100)])
+def test_hysteresis_parity(ctx, shape, lohi):
+    h, w = shape
+    lo, hi = lohi
+    rng = np.random.default_rng(9)
+    for density in (0.05, 0.3, 0.9):
+        cand = rng.integers(0, 256, size=(h, w), dtype=np.int16)
+        cand[rng.random((h, w)) > density] = 0
+        assert np.array_equal(ctx.hysteresis(cand, lo, hi), oracle.hysteresis(cand, lo, hi)), (shape, lohi, density)
+
+
+def test_hysteresis_directed_quirk(ctx):
+    """(1,0) never pushes (0,1) (src/utils.cpp:378,399) but (0,1) pushes (1,0)."""
+    a = np.zeros((4, 4), np.int16)
+    a[2, 0], a[1, 0], a[0, 1] = 200, 60, 60
+    out = ctx.hysteresis(a, 50, 150)
+    assert np.array_equal(out, oracle.hysteresis(a, 50, 150)) and out[0, 1] == 0 and out[1, 0] == 255
+    b = np.zeros((4, 4), np.int16)
+    b[0, 2], b[0, 1], b[1, 0] = 200, 60, 60
+    out = ctx.hysteresis(b, 50, 150)
+    assert np.array_equal(out, oracle.hysteresis(b, 50, 150)) and out[1, 0] == 255
+    # the quirk pixel pair inside a larger image and with other ways round it
+    for seed in range(20):
+        rng = np.random.default_rng(100 + seed)
+        c = (rng.random((6, 6)) < 0.45).astype(np.int16) * 60
+        c[rng.integers(0, 6), rng.integers(0, 6)] = 200
+        assert np.array_equal(ctx.hysteresis(c, 50, 150), oracle.hysteresis(c, 50, 150)), seed
+
+
+def test_hysteresis_long_paths_cross_many_tiles(ctx):
+    """A serpentine one-pixel path through a 200x330 image: thousands of steps, dozens of 64x64 tiles."""
+    h, w = 200, 330
+    cand = np.zeros((h, w), np.int16)
+    for r in range(0, h, 4):
+        cand[r, :] = 60
+        if (r // 4) % 2 == 0:
+            cand[r:r + 4, w - 1] = 60
+        else:
+            cand[r:r + 4, 0] = 60
+    cand[0, 0] = 250
+    want = oracle.hysteresis(cand, 50, 150)
+    got = ctx.hysteresis(cand, 50, 150)
+    assert np.array_equal(got, want)
+    assert np.count_nonzero(got) == np.count_nonzero(cand)     # everything is reached
+    assert ctx.last_hysteresis_iterations > 4
+    # break the path: nothing beyond the gap may be reached
+    cand[100, 150] = 0
+    assert np.array_equal(ctx.hysteresis(cand, 50, 150), oracle.hysteresis(cand, 50, 150))
+
+
+def test_hysteresis_rejects_order_dependent_domain(ctx, hip):
+    a = np.array([[-5, 10], [3, 0]], np.int16)
+    with pytest.raises(hip.CannyHipError) as ei:
+        ctx.hysteresis(a, -1, 5)
+    assert ei.value.status == 5
+
+
+@pytest.mark.parametrize("shape", [(5, 5), (20, 31), (64, 64), (70, 130)])
+def test_find_edge_pixels_parity(ctx, shape):
+    h, w = shape
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        cand = rng.integers(0, 40, size=(h, w), dtype=np.int16)
+        cand[rng.random((h, w)) > 0.55] = 0
+        visited = (rng.random((h, w)) < 0.1).astype(np.uint8)
+        start = int(rng.integers(0, h * w))
+        lo = int(rng.integers(1, 20))
+        got_c, got_v = ctx.find_edge_pixels(cand, visited, start, lo, 30)
+        want_c, want_v = oracle.find_edge_pixels(cand, visited, start, lo, 30)
+        assert np.array_equal(got_c, want_c), (shape, trial)
+        assert np.array_equal(got_v, want_v), (shape, trial)
+
+
+# ---------------------------------------------------------------------------------------------
+# 4. Whole pipeline
+# ---------------------------------------------------------------------------------------------
+def test_pipeline_matches_committed_oracle_hashes(ctx, oracle_hashes, fixture_image):
+    inputs = {
+        "fixture256_s0.5_50_150": fixture_image, "fixture256_s1.0_50_150": fixture_image,
+        "synth_97x131_seed7_s1.4_50_150": synth_frame(97, 131, 7),
+        "synth_240x320_seed42_s2.0_30_90": synth_frame(240, 320, 42),
+        "synth_64x64_seed3_s0.5_10_50": synth_frame(64, 64, 3),
+    }
+    for name, want in oracle_hashes.items():
+        img = inputs[name]
+        sm = ctx.gaussian(img, want["sigma"])
+        assert _sha(sm) == want["smoothed_sha256"], name
+        mag, ang = ctx.sobel(sm)
+        assert _sha(mag) == want["magnitude_sha256"] and _sha(ang) == want["angle_sha256"], name
+        nm = ctx.nms(mag, ang)
+        assert _sha(nm) == want["nms_sha256"], name
+        assert _sha(ctx.hysteresis(nm, want["min"], want["max"])) == want["edges_sha256"], name
+        assert _sha(ctx.canny(img, want["sigma"], want["min"], want["max"])) == want["edges_sha256"], name
+
+
+@pytest.mark.parametrize("shape,sigma", [((2, 2), 1.0), ((37, 53), 0.5), ((97, 131), 1.4), ((256, 256), 1.0),
+                                         ((300, 500), 2.0), ((480, 640), 0.5), ((1080, 1920), 1.0)])
+def test_canny_end_to_end_parity(ctx, shape, sigma):
+    img = _mixed(shape[0], shape[1], 21)
+    assert np.array_equal(ctx.canny(img, sigma, 50, 150), oracle.canny(img, sigma, 50, 150))
+
+
+def test_canny_4k_full_size_parity_and_properties(ctx):
+    """BASELINE config 2 at full size (3840x2160, sigma 1.4): every stage compared with the oracle
+    (about 1.5 s of CPU), plus size-independent properties."""
+    h, w = 2160, 3840
+    img = synth_frame(h, w, 42)
+    ref = oracle.canny(img, 1.4, 50, 150, stages=True)
+    sm = ctx.gaussian(img, 1.4)
+    assert np.array_equal(sm, ref["smoothed"])
+    d_in, d_out = ctx.malloc(sm.nbytes), ctx.malloc(sm.nbytes)
+    try:
+        ctx.h2d(d_in, sm)
+        ctx.dev_sobel_nms(d_in, h, w, 1, d_out)
+        nm = np.empty_like(sm)
+        ctx.d2h(nm, d_out)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    assert np.array_equal(nm, ref["nms"])
+    edges = ctx.canny(img, 1.4, 50, 150)
+    assert np.array_equal(edges, ref["edges"])
+    assert set(np.unique(edges)) <= {0, 255} and 0 < np.count_nonzero(edges) < edges.size // 10
+    # idempotence: a finished edge map is a fixed point of hysteresis
+    assert np.array_equal(ctx.hysteresis(edges, 50, 150), edges)
+    # monotonicity in the strong threshold: raising max can only remove edge pixels
+    fewer = ctx.hysteresis(nm, 50, 200)
+    assert np.all(edges[fewer == 255] == 255)
+
+
+def test_canny_16k_tile_properties(ctx):
+    """BASELINE config 4 (16384x16384, sigma 2.0) is too big for the oracle to finish in seconds, so the
+    whole frame is checked through properties and a 700-row band is compared with the oracle exactly
+    (the band's interior is independent of the rest of the image except through hysteresis, so the
+    band is compared on the smoothed and NMS planes)."""
+    h = w = 16384
+    rng = np.random.default_rng(5)
+    small = synth_frame(1024, 1024, 9)
+    img = np.tile(small, (16, 16))
+    img[rng.integers(0, h, 4000), rng.integers(0, w, 4000)] = 255
+    edges = ctx.canny(img, 2.0, 50, 150)
+    assert edges.shape == (h, w) and set(np.unique(edges)) <= {0, 255}
+    assert np.array_equal(ctx.hysteresis(edges, 50, 150), edges)
+    band = img[5000:5700]                          # rows 5000..5699
+    sm_band = oracle.gaussian(band, 2.0)
+    sm_full = ctx.gaussian(img, 2.0)
+    assert np.array_equal(sm_full[5006:5694], sm_band[6:694])   # away from the band's own top/bottom border
+    nm_band = oracle.nms(*oracle.sobel(sm_full[5000:5700]))
+    d_in, d_out = ctx.malloc(sm_full.nbytes), ctx.malloc(sm_full.nbytes)
+    try:
+        ctx.h2d(d_in, sm_full)
+        ctx.dev_sobel_nms(d_in, h, w, 1, d_out)
+        nm = np.empty_like(sm_full)
+        ctx.d2h(nm, d_out)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    assert np.array_equal(nm[5002:5698], nm_band[2:698])
+
+
+def test_batch_and_multi_gpu_entry_points(ctx, hip):
+    frames = np.stack([_mixed(120, 200, 30 + i) for i in range(7)])
+    want = np.stack([oracle.canny(f, 1.0, 50, 150) for f in frames])
+    assert np.array_equal(ctx.canny_batch(frames, 1.0, 50, 150), want)
+    assert np.array_equal(hip.canny_multi_gpu(frames, 1.0, 50, 150, 0), want)
+    # device-resident batch: all frames in one launch per stage
+    d_in, d_out = ctx.malloc(frames.nbytes), ctx.malloc(frames.nbytes * 2)
+    try:
+        ctx.h2d(d_in, frames)
+        ctx.dev_canny(d_in, 1.0, 50, 150, 120, 200, 7, d_out)
+        got = np.empty(frames.shape, np.int16)
+        ctx.d2h(got, d_out)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    assert np.array_equal(got, want)
+
+
+def test_stage_profile_counts_launches(ctx):
+    img = _mixed(200, 300, 40)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(3):
+        ctx.canny(img, 1.0, 50, 150)
+    ms, n = ctx.profile_get(1)  # fused sobel+nms
+    ctx.profile_enable(False)
+    assert n == 3 and ms > 0.0
+
+
+def test_invalid_arguments_are_rejected(ctx, hip):
+    with pytest.raises(hip.CannyHipError):
+        ctx.gaussian(np.zeros((4, 4), np.uint8), 0.0)
+    with pytest.raises(hip.CannyHipError):
+        ctx.sobel(np.zeros((1, 5), np.int16))      # the reference reads out of bounds for H < 2
+    with pytest.raises(hip.CannyHipError):
+        ctx.find_edge_pixels(np.zeros((3, 3), np.int16), np.zeros((3, 3), np.uint8), 9, 1, 2)

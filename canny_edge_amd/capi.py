@@ -33,7 +33,7 @@ STAGE_NAMES = ("gaussian", "sobel_nms", "hyst_classify", "hyst_propagate", "hyst
 # every symbol include/canny_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
     "canny_hip_version", "canny_hip_status_string", "canny_hip_device_count", "canny_hip_ctx_create",
-    "canny_hip_ctx_destroy", "canny_hip_ctx_set_stream", "canny_hip_ctx_device", "canny_hip_synchronize",
+    "canny_hip_ctx_destroy", "canny_hip_ctx_set_stream", "canny_hip_ctx_device", "canny_hip_ctx_set_option", "canny_hip_synchronize",
     "canny_hip_last_error", "canny_hip_last_hysteresis_iterations", "canny_hip_malloc", "canny_hip_free",
     "canny_hip_host_alloc", "canny_hip_host_free", "canny_hip_memcpy_h2d", "canny_hip_memcpy_d2h",
     "canny_hip_gaussian_kernel", "canny_hip_gaussian", "canny_hip_xy_gradient", "canny_hip_sobel", "canny_hip_nms",
@@ -75,6 +75,7 @@ def load() -> C.CDLL:
         "canny_hip_ctx_destroy": ([p], None),
         "canny_hip_ctx_set_stream": ([p, p], i),
         "canny_hip_ctx_device": ([p], i),
+        "canny_hip_ctx_set_option": ([p, C.c_char_p, i], i),
         "canny_hip_synchronize": ([p], i),
         "canny_hip_last_error": ([p], C.c_char_p),
         "canny_hip_last_hysteresis_iterations": ([p], i),
@@ -188,6 +189,10 @@ class Context:
     def set_stream(self, hip_stream: int):
         """Launch on a caller-owned hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
         self._check(self._L.canny_hip_ctx_set_stream(self._h, C.c_void_p(hip_stream)), "set_stream")
+
+    def set_option(self, name: str, value: int):
+        """Kernel-path selection ("gaussian_path" / "sobel_nms_path": 0 auto, 1 baseline, 2 wave-marching)."""
+        self._check(self._L.canny_hip_ctx_set_option(self._h, name.encode(), value), f"set_option({name})")
 
     def synchronize(self):
         self._check(self._L.canny_hip_synchronize(self._h), "synchronize")

@@ -67,6 +67,8 @@ struct canny_hip_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
     int last_hyst_iters = 0;
+    int gaussian_path = 0;   // 0 auto, 1 generic, 2 march
+    int sobel_nms_path = 0;  // 0 auto, 1 LDS tile, 2 march
 
     // device workspaces
     DevBuf tmp_f32;   // generic Gaussian row-pass plane
@@ -173,7 +175,9 @@ int dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, in
     int rc = make_taps(sigma, taps);
     if (rc) return rc;
     StageTimer tm(ctx, CANNY_HIP_STAGE_GAUSSIAN);
-    if (gaussian_march_supported(taps.center, h, w)) {
+    const bool can_march = gaussian_march_supported(taps.center, h, w);
+    if (ctx->gaussian_path == 2 && !can_march) return CANNY_HIP_ERR_UNSUPPORTED;
+    if (can_march && ctx->gaussian_path != 1) {
         HIP_TRY(ctx, launch_gaussian_march(d_img, d_out, h, w, n, taps, ctx->stream));
     } else {
         HIP_TRY(ctx, ctx->tmp_f32.ensure(npx(h, w, n) * sizeof(float)));
@@ -241,6 +245,17 @@ int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int l
     return CANNY_HIP_OK;
 }
 
+// Fused Sobel+NMS on a smoothed plane in [0,255].
+int dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int h, int w, int n, short *d_out)
+{
+    StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+    if (ctx->sobel_nms_path != 1 && sobel_nms_march_supported(h, w))
+        HIP_TRY(ctx, launch_sobel_nms_march(d_smoothed, d_out, h, w, n, ctx->stream));
+    else
+        HIP_TRY(ctx, launch_sobel_nms(d_smoothed, d_out, h, w, n, /*domain8=*/true, ctx->stream));
+    return CANNY_HIP_OK;
+}
+
 int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int lo, int hi, int h, int w, int n,
               short *d_edges)
 {
@@ -249,10 +264,7 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
     short *sm = (short *)ctx->smoothed.p;
     int rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm);
     if (rc) return rc;
-    {
-        StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
-        HIP_TRY(ctx, launch_sobel_nms(sm, d_edges, h, w, n, /*domain8=*/true, ctx->stream));
-    }
+    if ((rc = dev_sobel_nms(ctx, sm, h, w, n, d_edges))) return rc;
     return dev_hysteresis(ctx, d_edges, h, w, n, lo, hi);
 }
 
@@ -364,6 +376,15 @@ int canny_hip_ctx_set_stream(canny_hip_ctx *ctx, void *hip_stream)
 }
 
 int canny_hip_ctx_device(const canny_hip_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name || value < 0 || value > 2) return CANNY_HIP_ERR_INVALID;
+    if (!std::strcmp(name, "gaussian_path")) ctx->gaussian_path = value;
+    else if (!std::strcmp(name, "sobel_nms_path")) ctx->sobel_nms_path = value;
+    else return CANNY_HIP_ERR_INVALID;
+    return CANNY_HIP_OK;
+}
 
 int canny_hip_synchronize(canny_hip_ctx *ctx)
 {
@@ -746,9 +767,7 @@ int canny_hip_dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int hei
     if (!d_smoothed || !d_nms) return CANNY_HIP_ERR_INVALID;
     if ((rc = check_dims(height, width, n_frames))) return rc;
     if (height < 2 || width < 2) return CANNY_HIP_ERR_UNSUPPORTED;
-    StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
-    HIP_TRY(ctx, launch_sobel_nms(d_smoothed, d_nms, height, width, n_frames, /*domain8=*/true, ctx->stream));
-    return CANNY_HIP_OK;
+    return dev_sobel_nms(ctx, d_smoothed, height, width, n_frames, d_nms);
 }
 
 int canny_hip_dev_hysteresis(canny_hip_ctx *ctx, short *d_edge_candidates, int height, int width, int n_frames,

@@ -1,0 +1,224 @@
+#include "canny_kernels.h"
+namespace canny {
+
+// ================================================================================================
+// Gaussian, wave-marching path (window <= 17).
+//
+// One WAVE owns a strip of (64-2*HL)*4 output columns and marches down a segment of rows; the
+// four waves of a workgroup are independent (no __syncthreads anywhere).  Per input row:
+//   1. each lane loads 4 u8 pixels (one dword), converts them once and publishes the 4 floats in a
+//      per-wave LDS row buffer; neighbours' pixels come back as aligned ds_read_b128 (halo exchange
+//      through LDS, wave-scope fences only);
+//   2. row pass: 4 outputs per lane, taps in ascending order, separately rounded mul/add, IEEE
+//      divide by the (per-column, precomputed) weight -> written to the lane's private column ring
+//      in LDS (2C+1 rows);
+//   3. once 2C+1 rows are in the ring the column pass produces one output row: taps in ascending
+//      row order out of the ring, IEEE divide by the (per-row) weight, truncate, one 8-byte store.
+// Out-of-image pixels/rows enter the sums as +0.0f products, which leaves every partial sum
+// bit-identical to the reference's "skip the tap" (x + 0 == x exactly for x >= 0); only the weight
+// has to be the sum over the in-image taps, accumulated in the reference's ascending order.
+// HBM traffic: 1 B/px in + 2 B/px out; the f32 intermediate never leaves the CU.
+// ================================================================================================
+template <int C>
+struct MarchCfg {
+    static constexpr int HL = (C + 3) / 4;             // halo lanes per side (4 px each)
+    static constexpr int RING = 2 * C + 1;             // rows in the column ring
+    static constexpr int WIN = 4 + 8 * HL;             // floats a lane reads back per row
+    static constexpr int SW = (64 - 2 * HL) * 4;       // output columns per strip
+    static constexpr int ROWBUF = (64 + 2 * HL) * 4;   // floats
+    static constexpr int WAVE_FLOATS = ROWBUF + RING * 256;
+    static constexpr int WPB = (C <= 6) ? 4 : 2;       // waves per workgroup (LDS budget)
+};
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int C>
+__global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
+    const uint8_t *__restrict__ img, int16_t *__restrict__ out, int H, int W, int n_strips, int n_segs, int seg_rows,
+    int total_waves, GaussTaps t)
+{
+    using K = MarchCfg<C>;
+    constexpr int HL = K::HL, RING = K::RING, WIN = K::WIN;
+    __shared__ __attribute__((aligned(16))) float lds[K::WPB * K::WAVE_FLOATS];
+
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wave = blockIdx.x * K::WPB + wib;
+    if (wave >= total_waves) return;
+    float *rowbuf = lds + wib * K::WAVE_FLOATS;
+    float *colring = rowbuf + K::ROWBUF + lane * 4; // this lane's 4 columns, slot stride 256 floats
+
+    const int s = wave % n_strips;
+    const int g = (wave / n_strips) % n_segs;
+    const int f = wave / (n_strips * n_segs);
+    const int ybeg = g * seg_rows;
+    const int yend = min(H, ybeg + seg_rows);
+    const int x0 = s * K::SW + (lane - HL) * 4; // first of this lane's 4 columns (halo lanes may be outside)
+    const bool owner = lane >= HL && lane < 64 - HL && x0 < W;
+    const bool full4 = x0 >= 0 && x0 + 3 < W;
+    const uint8_t *fimg = img + (size_t)f * H * W;
+    int16_t *fout = out + (size_t)f * H * W;
+
+    // weights: full window, and this lane's four per-column weights (in-image taps, ascending)
+    float cnt_full = t.tap[0];
+#pragma unroll
+    for (int k = 1; k < RING; k++) cnt_full = __fadd_rn(cnt_full, t.tap[k]);
+    float cnt_h[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int x = x0 + j;
+        float c = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RING; k++) {
+            int xx = x + k - C;
+            if (xx >= 0 && xx < W) c = __fadd_rn(c, t.tap[k]);
+        }
+        cnt_h[j] = (x >= 0 && x < W) ? c : 1.0f;
+    }
+
+    if (lane < 4 * HL) { // the pads of the row buffer are only ever read by halo lanes; keep them finite
+        rowbuf[lane] = 0.0f;
+        rowbuf[(64 + HL) * 4 + lane] = 0.0f;
+    }
+
+    auto load_row = [&](int r) -> uint32_t {
+        if (r < 0 || r >= H) return 0u; // wave-uniform
+        const uint8_t *p = fimg + (size_t)r * W;
+        uint32_t v = 0u;
+        if (full4) {
+            __builtin_memcpy(&v, p + x0, 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int x = x0 + j;
+                if (x >= 0 && x < W) v |= (uint32_t)p[x] << (8 * j);
+            }
+        }
+        return v;
+    };
+
+    const int rfirst = ybeg - C, rlast = yend - 1 + C;
+    uint32_t cur = load_row(rfirst), nxt = load_row(rfirst + 1);
+    int wslot = 0; // ring slot the next row-pass result goes to
+    int oslot = 0; // ring slot holding tap 0 of the next output row
+    for (int r = rfirst; r <= rlast; r++) {
+        const uint32_t nn = load_row(r + 2);
+        float4 tmp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (r >= 0 && r < H) { // wave-uniform
+            float4 own = make_float4((float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
+                                     (float)(cur >> 24));
+            *reinterpret_cast<float4 *>(rowbuf + (lane + HL) * 4) = own;
+            wave_lds_fence();
+            float wv[WIN];
+#pragma unroll
+            for (int q = 0; q < WIN / 4; q++) {
+                float4 v = *reinterpret_cast<const float4 *>(rowbuf + lane * 4 + q * 4);
+                wv[4 * q + 0] = v.x;
+                wv[4 * q + 1] = v.y;
+                wv[4 * q + 2] = v.z;
+                wv[4 * q + 3] = v.w;
+            }
+            wave_lds_fence();
+            float res[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float acc = __fmul_rn(wv[4 * HL + j - C], t.tap[0]);
+#pragma unroll
+                for (int k = 1; k < RING; k++) acc = __fadd_rn(acc, __fmul_rn(wv[4 * HL + j - C + k], t.tap[k]));
+                res[j] = __fdiv_rn(acc, cnt_h[j]);
+            }
+            tmp = make_float4(res[0], res[1], res[2], res[3]);
+        }
+        *reinterpret_cast<float4 *>(colring + wslot * 256) = tmp;
+        wslot = (wslot + 1 == RING) ? 0 : wslot + 1;
+
+        const int y = r - C; // the output row whose last tap just arrived
+        if (y >= ybeg) {
+            float cnt_v = cnt_full;
+            if (y < C || y + C >= H) { // wave-uniform: top/bottom border rows renormalise
+                cnt_v = 0.0f;
+                for (int k = 0; k < RING; k++) {
+                    int yy = y + k - C;
+                    if (yy >= 0 && yy < H) cnt_v = __fadd_rn(cnt_v, t.tap[k]);
+                }
+            }
+            float acc[4];
+#pragma unroll
+            for (int k = 0; k < RING; k++) {
+                int slot = oslot + k;
+                slot = slot >= RING ? slot - RING : slot;
+                float4 v = *reinterpret_cast<const float4 *>(colring + slot * 256);
+                if (k == 0) {
+                    acc[0] = __fmul_rn(v.x, t.tap[0]);
+                    acc[1] = __fmul_rn(v.y, t.tap[0]);
+                    acc[2] = __fmul_rn(v.z, t.tap[0]);
+                    acc[3] = __fmul_rn(v.w, t.tap[0]);
+                } else {
+                    acc[0] = __fadd_rn(acc[0], __fmul_rn(v.x, t.tap[k]));
+                    acc[1] = __fadd_rn(acc[1], __fmul_rn(v.y, t.tap[k]));
+                    acc[2] = __fadd_rn(acc[2], __fmul_rn(v.z, t.tap[k]));
+                    acc[3] = __fadd_rn(acc[3], __fmul_rn(v.w, t.tap[k]));
+                }
+            }
+            oslot = (oslot + 1 == RING) ? 0 : oslot + 1;
+            if (owner) {
+                int16_t o0 = (int16_t)__fdiv_rn(acc[0], cnt_v), o1 = (int16_t)__fdiv_rn(acc[1], cnt_v);
+                int16_t o2 = (int16_t)__fdiv_rn(acc[2], cnt_v), o3 = (int16_t)__fdiv_rn(acc[3], cnt_v);
+                int16_t *dst = fout + (size_t)y * W + x0;
+                if (full4) {
+                    uint2 pk;
+                    pk.x = (uint32_t)(uint16_t)o0 | ((uint32_t)(uint16_t)o1 << 16);
+                    pk.y = (uint32_t)(uint16_t)o2 | ((uint32_t)(uint16_t)o3 << 16);
+                    __builtin_memcpy(dst, &pk, 8);
+                } else {
+                    dst[0] = o0;
+                    if (x0 + 1 < W) dst[1] = o1;
+                    if (x0 + 2 < W) dst[2] = o2;
+                }
+            }
+        }
+        cur = nxt;
+        nxt = nn;
+    }
+}
+
+template <int C>
+static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, int width, int n_frames,
+                                 const GaussTaps &taps, hipStream_t stream)
+{
+    using K = MarchCfg<C>;
+    int n_strips = (width + K::SW - 1) / K::SW;
+    // longest segments that still give the chip a few thousand waves
+    int seg = 256;
+    while (seg > 32 && (long long)n_frames * n_strips * ((height + seg - 1) / seg) < 16384) seg >>= 1;
+    int n_segs = (height + seg - 1) / seg;
+    long long waves = (long long)n_frames * n_strips * n_segs;
+    if (waves > 0x7fffffffLL) return hipErrorInvalidValue;
+    unsigned blocks = (unsigned)((waves + K::WPB - 1) / K::WPB);
+    hipLaunchKernelGGL(gauss_march_kernel<C>, dim3(blocks), dim3(K::WPB * 64), 0, stream, img, out, height, width,
+                       n_strips, n_segs, seg, (int)waves, taps);
+    return hipGetLastError();
+}
+
+bool gaussian_march_supported(int center, int, int) { return center >= 1 && center <= 8; }
+
+hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, int width, int n_frames,
+                                 const GaussTaps &taps, hipStream_t stream)
+{
+    switch (taps.center) {
+    case 1: return launch_march_c<1>(img, out, height, width, n_frames, taps, stream);
+    case 2: return launch_march_c<2>(img, out, height, width, n_frames, taps, stream);
+    case 3: return launch_march_c<3>(img, out, height, width, n_frames, taps, stream);
+    case 4: return launch_march_c<4>(img, out, height, width, n_frames, taps, stream);
+    case 5: return launch_march_c<5>(img, out, height, width, n_frames, taps, stream);
+    case 6: return launch_march_c<6>(img, out, height, width, n_frames, taps, stream);
+    case 7: return launch_march_c<7>(img, out, height, width, n_frames, taps, stream);
+    case 8: return launch_march_c<8>(img, out, height, width, n_frames, taps, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
+} // namespace canny

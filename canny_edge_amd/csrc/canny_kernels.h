@@ -55,10 +55,14 @@ hipError_t launch_sobel(const int16_t *img, int16_t *mag, int16_t *angle, int he
                         hipStream_t stream);
 hipError_t launch_nms(const int16_t *mag, const int16_t *angle, int16_t *out, int height, int width, int n_frames,
                       hipStream_t stream);
-// Fused Sobel+NMS.  domain8 = smoothed plane known to lie in [0,255] (float sqrt + 24-bit products);
-// otherwise the general path (double sqrt, 64-bit products).
+// Fused Sobel+NMS, LDS-tiled.  domain8 = smoothed plane known to lie in [0,255] (float sqrt + 24-bit
+// products); otherwise the general path (double sqrt, 64-bit products).
 hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
                             bool domain8, hipStream_t stream);
+// Fused Sobel+NMS, wave-marching and LDS-free (canny_sobel_nms_march.hip); smoothed must lie in [0,255].
+bool sobel_nms_march_supported(int height, int width);
+hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
+                                  hipStream_t stream);
 
 // ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
 hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,

@@ -158,11 +158,7 @@ hipError_t launch_gaussian_generic(const uint8_t *img, float *tmp, int16_t *out,
     return hipGetLastError();
 }
 
-bool gaussian_march_supported(int, int, int) { return false; }
-hipError_t launch_gaussian_march(const uint8_t *, int16_t *, int, int, int, const GaussTaps &, hipStream_t)
-{
-    return hipErrorNotSupported;
-}
+// (the wave-marching Gaussian for windows <= 17 lives in canny_gaussian_march.hip)
 
 // ================================================================================================
 // Stand-alone Sobel / NMS stage kernels (general domain, one thread per pixel)

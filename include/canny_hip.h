@@ -88,6 +88,10 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx);
  * restores the context's own stream. */
 int canny_hip_ctx_set_stream(canny_hip_ctx *ctx, void *hip_stream);
 int canny_hip_ctx_device(const canny_hip_ctx *ctx);
+/* Kernel-path selection, for A/B measurements and tests; every path gives identical results.
+ *   "gaussian_path":  0 auto (default), 1 generic two-pass, 2 wave-marching (window <= 17)
+ *   "sobel_nms_path": 0 auto (default), 1 LDS-tiled, 2 wave-marching */
+int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value);
 int canny_hip_synchronize(canny_hip_ctx *ctx);
 /* Text of the last HIP runtime error seen by this context ("" if none). */
 const char *canny_hip_last_error(const canny_hip_ctx *ctx);

@@ -376,3 +376,61 @@ def test_invalid_arguments_are_rejected(ctx, hip):
         ctx.sobel(np.zeros((1, 5), np.int16))      # the reference reads out of bounds for H < 2
     with pytest.raises(hip.CannyHipError):
         ctx.find_edge_pixels(np.zeros((3, 3), np.int16), np.zeros((3, 3), np.uint8), 9, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# 5. Every kernel path (canny_hip_ctx_set_option) gives the same bits
+# ---------------------------------------------------------------------------------------------
+PATH_SHAPES = [(2, 2), (3, 70), (70, 3), (33, 250), (64, 496), (65, 497), (97, 505), (130, 1000), (300, 1240)]
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("sigma", [0.3, 0.5, 1.0, 1.4, 2.0, 2.6])
+def test_gaussian_paths(hip, path, sigma):
+    with hip.Context(0) as c:
+        c.set_option("gaussian_path", path)
+        for shape in PATH_SHAPES + [(1, 1), (1, 300), (300, 1), (700, 260)]:
+            for seed, gen in ((1, _noise), (2, _mixed)):
+                img = gen(shape[0], shape[1], seed)
+                assert np.array_equal(c.gaussian(img, sigma), oracle.gaussian(img, sigma)), (path, sigma, shape, seed)
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_sobel_nms_paths(hip, path):
+    with hip.Context(0) as c:
+        c.set_option("sobel_nms_path", path)
+        for shape in PATH_SHAPES + [(2, 3), (5, 8), (9, 9), (40, 1489), (600, 130)]:
+            h, w = shape
+            for seed in (7, 8, 9):
+                sm = oracle.gaussian(_mixed(h, w, seed) if seed != 9 else _noise(h, w, seed), 0.5)
+                want = oracle.nms(*oracle.sobel(sm))
+                d_in, d_out = c.malloc(sm.nbytes), c.malloc(sm.nbytes)
+                try:
+                    c.h2d(d_in, sm)
+                    c.dev_sobel_nms(d_in, h, w, 1, d_out)
+                    got = np.empty_like(sm)
+                    c.d2h(got, d_out)
+                finally:
+                    c.free(d_in)
+                    c.free(d_out)
+                bad = np.argwhere(got != want)
+                assert bad.size == 0, (path, shape, seed, bad[:5].tolist())
+
+
+@pytest.mark.parametrize("gpath,spath", [(1, 1), (2, 2)])
+def test_pipeline_paths_batched(hip, gpath, spath):
+    frames = np.stack([_mixed(270, 520, 50 + i) for i in range(5)])
+    want = np.stack([oracle.canny(f, 1.4, 50, 150) for f in frames])
+    with hip.Context(0) as c:
+        c.set_option("gaussian_path", gpath)
+        c.set_option("sobel_nms_path", spath)
+        d_in, d_out = c.malloc(frames.nbytes), c.malloc(frames.nbytes * 2)
+        try:
+            c.h2d(d_in, frames)
+            c.dev_canny(d_in, 1.4, 50, 150, 270, 520, 5, d_out)
+            got = np.empty(frames.shape, np.int16)
+            c.d2h(got, d_out)
+        finally:
+            c.free(d_in)
+            c.free(d_out)
+        assert np.array_equal(got, want)

@@ -41,7 +41,7 @@ EXPORTS = (
     "canny_hip_canny_multi_gpu", "canny_hip_shard_range", "canny_hip_dev_gaussian", "canny_hip_dev_xy_gradient",
     "canny_hip_dev_sobel", "canny_hip_dev_nms", "canny_hip_dev_sobel_nms", "canny_hip_dev_hysteresis",
     "canny_hip_dev_canny", "canny_hip_profile_enable", "canny_hip_profile_reset", "canny_hip_profile_get",
-    "canny_hip_selftest_mag_angle",
+    "canny_hip_selftest_mag_angle", "canny_hip_selftest_div",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -107,6 +107,7 @@ def load() -> C.CDLL:
         "canny_hip_profile_reset": ([p], i),
         "canny_hip_profile_get": ([p, i, C.POINTER(C.c_double), C.POINTER(C.c_long)], i),
         "canny_hip_selftest_mag_angle": ([p, i, p, p], i),
+        "canny_hip_selftest_div": ([p, f, C.POINTER(C.c_ulonglong)], i),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -291,6 +292,12 @@ class Context:
         bins = np.empty((side, side), np.uint8)
         self._check(self._L.canny_hip_selftest_mag_angle(self._h, lim, _hp(mags), _hp(bins)), "selftest")
         return mags, bins
+
+    def selftest_div(self, divisor: float) -> int:
+        """Mismatches between the Gaussian's reciprocal division and IEEE a/divisor over all a in [0,256]."""
+        bad = C.c_ulonglong(0)
+        self._check(self._L.canny_hip_selftest_div(self._h, divisor, C.byref(bad)), "selftest_div")
+        return bad.value
 
     # ---- device-pointer stage API (ints are device addresses; n_frames contiguous planes) -------
     def dev_gaussian(self, d_img: int, sigma: float, h: int, w: int, n: int, d_out: int):

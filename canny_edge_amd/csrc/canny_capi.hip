@@ -854,4 +854,16 @@ int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes,
     return d2h_sync(ctx, bins, ctx->io[1].p, total);
 }
 
+int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!mismatches || !(divisor > 0.0f) || !std::isfinite(divisor)) return CANNY_HIP_ERR_INVALID;
+    HIP_TRY(ctx, ctx->io[0].ensure(sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io[0].p, 0, sizeof(unsigned long long), ctx->stream));
+    const unsigned last = 0x43800000u; // bit pattern of 256.0f; non-negative floats are ordered like their bits
+    HIP_TRY(ctx, launch_selftest_div(divisor, 0u, last, (unsigned long long *)ctx->io[0].p, ctx->stream));
+    return d2h_sync(ctx, mismatches, ctx->io[0].p, sizeof(unsigned long long));
+}
+
 } // extern "C"

@@ -1,33 +1,46 @@
-#include "canny_kernels.h"
-namespace canny {
-
-// ================================================================================================
-// Gaussian, wave-marching path (window <= 17).
+// canny_gaussian_march.hip -- separable Gaussian, wave-marching path (window <= 17).
 //
-// One WAVE owns a strip of (64-2*HL)*4 output columns and marches down a segment of rows; the
-// four waves of a workgroup are independent (no __syncthreads anywhere).  Per input row:
+// One WAVE owns a strip of (64-2*HL)*4 output columns and marches down a segment of rows; the waves
+// of a workgroup are independent (no __syncthreads anywhere).  Per input row:
 //   1. each lane loads 4 u8 pixels (one dword), converts them once and publishes the 4 floats in a
 //      per-wave LDS row buffer; neighbours' pixels come back as aligned ds_read_b128 (halo exchange
 //      through LDS, wave-scope fences only);
-//   2. row pass: 4 outputs per lane, taps in ascending order, separately rounded mul/add, IEEE
-//      divide by the (per-column, precomputed) weight -> written to the lane's private column ring
-//      in LDS (2C+1 rows);
+//   2. row pass: 4 outputs per lane, taps in ascending order, separately rounded mul/add, exact
+//      division by the per-column weight -> written to the lane's private column ring in LDS;
 //   3. once 2C+1 rows are in the ring the column pass produces one output row: taps in ascending
-//      row order out of the ring, IEEE divide by the (per-row) weight, truncate, one 8-byte store.
-// Out-of-image pixels/rows enter the sums as +0.0f products, which leaves every partial sum
-// bit-identical to the reference's "skip the tap" (x + 0 == x exactly for x >= 0); only the weight
-// has to be the sum over the in-image taps, accumulated in the reference's ascending order.
+//      row order out of the ring, exact division by the per-row weight, truncate, one 8-byte store.
+//
+// Bit-exactness (reference src/utils.cpp:37-64):
+//   * Out-of-image pixels/rows enter the sums as +0.0f products, which leaves every partial sum
+//     bit-identical to the reference's "skip the tap" (x + 0 == x exactly for x >= 0); only the weight
+//     has to be the sum over the in-image taps, accumulated in the reference's ascending order.
+//   * a / b is computed as the tail of the hardware's own IEEE-754 division expansion
+//     (q0 = a*y, two residual corrections with fma) with y = RN(1/b) obtained once from a true IEEE
+//     division; a in [0,256], b in (0,1.01] so no scaling is needed.  canny_hip_selftest_div checks it
+//     against __fdiv_rn over every float in [0,256] for the weights of a sigma sweep.
 // HBM traffic: 1 B/px in + 2 B/px out; the f32 intermediate never leaves the CU.
-// ================================================================================================
+//
+// COL_EDGE / ROW_EDGE instantiations: waves whose strip touches column 0 / W-1 or whose segment touches
+// row 0 / H-1 carry the border logic; all others run straight-line code with unconditional loads and a
+// single wave-uniform weight.  The wave index goes through readfirstlane so that rows and ring slots live
+// in SGPRs.
+#include "canny_kernels.h"
+
+#include <type_traits>
+
+namespace canny {
+
+namespace {
+
 template <int C>
 struct MarchCfg {
-    static constexpr int HL = (C + 3) / 4;             // halo lanes per side (4 px each)
-    static constexpr int RING = 2 * C + 1;             // rows in the column ring
-    static constexpr int WIN = 4 + 8 * HL;             // floats a lane reads back per row
-    static constexpr int SW = (64 - 2 * HL) * 4;       // output columns per strip
-    static constexpr int ROWBUF = (64 + 2 * HL) * 4;   // floats
+    static constexpr int HL = (C + 3) / 4;           // halo lanes per side (4 px each)
+    static constexpr int RING = 2 * C + 1;           // rows in the column ring
+    static constexpr int WIN = 4 + 8 * HL;           // floats a lane reads back per row
+    static constexpr int SW = (64 - 2 * HL) * 4;     // output columns per strip
+    static constexpr int ROWBUF = (64 + 2 * HL) * 4; // floats
     static constexpr int WAVE_FLOATS = ROWBUF + RING * 256;
-    static constexpr int WPB = (C <= 6) ? 4 : 2;       // waves per workgroup (LDS budget)
+    static constexpr int WPB = (C <= 6) ? 4 : 2;     // waves per workgroup (LDS budget)
 };
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -36,59 +49,65 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int C>
-__global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
-    const uint8_t *__restrict__ img, int16_t *__restrict__ out, int H, int W, int n_strips, int n_segs, int seg_rows,
-    int total_waves, GaussTaps t)
+// Correctly rounded a / b given y = RN(1/b): the refinement tail of the IEEE division sequence.
+__device__ __forceinline__ float div_by(float a, float b, float y)
+{
+    float q = __fmul_rn(a, y);
+    float r = __fmaf_rn(-q, b, a);
+    q = __fmaf_rn(r, y, q);
+    r = __fmaf_rn(-q, b, a);
+    return __fmaf_rn(r, y, q);
+}
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+struct GaussJob {
+    const uint8_t *fimg;
+    int16_t *fout;
+    int H, W, ybeg, yend, x0, lane;
+};
+
+template <int C, bool COL_EDGE, bool ROW_EDGE>
+__device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const GaussTaps &t, float *rowbuf, float *colring)
 {
     using K = MarchCfg<C>;
     constexpr int HL = K::HL, RING = K::RING, WIN = K::WIN;
-    __shared__ __attribute__((aligned(16))) float lds[K::WPB * K::WAVE_FLOATS];
-
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int wave = blockIdx.x * K::WPB + wib;
-    if (wave >= total_waves) return;
-    float *rowbuf = lds + wib * K::WAVE_FLOATS;
-    float *colring = rowbuf + K::ROWBUF + lane * 4; // this lane's 4 columns, slot stride 256 floats
-
-    const int s = wave % n_strips;
-    const int g = (wave / n_strips) % n_segs;
-    const int f = wave / (n_strips * n_segs);
-    const int ybeg = g * seg_rows;
-    const int yend = min(H, ybeg + seg_rows);
-    const int x0 = s * K::SW + (lane - HL) * 4; // first of this lane's 4 columns (halo lanes may be outside)
+    const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend, lane = jb.lane;
     const bool owner = lane >= HL && lane < 64 - HL && x0 < W;
     const bool full4 = x0 >= 0 && x0 + 3 < W;
-    const uint8_t *fimg = img + (size_t)f * H * W;
-    int16_t *fout = out + (size_t)f * H * W;
 
-    // weights: full window, and this lane's four per-column weights (in-image taps, ascending)
+    // weights: full window (wave-uniform) and, at the column borders, this lane's four own weights
     float cnt_full = t.tap[0];
 #pragma unroll
     for (int k = 1; k < RING; k++) cnt_full = __fadd_rn(cnt_full, t.tap[k]);
-    float cnt_h[4];
+    const float inv_full = __fdiv_rn(1.0f, cnt_full);
+    float cnt_h[4], inv_h[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        int x = x0 + j;
-        float c = 0.0f;
-#pragma unroll
-        for (int k = 0; k < RING; k++) {
-            int xx = x + k - C;
-            if (xx >= 0 && xx < W) c = __fadd_rn(c, t.tap[k]);
-        }
-        cnt_h[j] = (x >= 0 && x < W) ? c : 1.0f;
+        cnt_h[j] = cnt_full;
+        inv_h[j] = inv_full;
     }
-
-    if (lane < 4 * HL) { // the pads of the row buffer are only ever read by halo lanes; keep them finite
-        rowbuf[lane] = 0.0f;
-        rowbuf[(64 + HL) * 4 + lane] = 0.0f;
+    if (COL_EDGE) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = x0 + j;
+            float c = 0.0f;
+#pragma unroll
+            for (int k = 0; k < RING; k++) {
+                int xx = x + k - C;
+                if (xx >= 0 && xx < W) c = __fadd_rn(c, t.tap[k]);
+            }
+            cnt_h[j] = (x >= 0 && x < W) ? c : 1.0f;
+            inv_h[j] = __fdiv_rn(1.0f, cnt_h[j]);
+        }
     }
 
     auto load_row = [&](int r) -> uint32_t {
-        if (r < 0 || r >= H) return 0u; // wave-uniform
-        const uint8_t *p = fimg + (size_t)r * W;
+        if (ROW_EDGE && (r < 0 || r >= H)) return 0u; // wave-uniform
+        const uint8_t *p = jb.fimg + (size_t)r * W;
         uint32_t v = 0u;
-        if (full4) {
+        if (!COL_EDGE || full4) {
             __builtin_memcpy(&v, p + x0, 4);
         } else {
 #pragma unroll
@@ -100,14 +119,13 @@ __global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
         return v;
     };
 
-    const int rfirst = ybeg - C, rlast = yend - 1 + C;
-    uint32_t cur = load_row(rfirst), nxt = load_row(rfirst + 1);
     int wslot = 0; // ring slot the next row-pass result goes to
     int oslot = 0; // ring slot holding tap 0 of the next output row
-    for (int r = rfirst; r <= rlast; r++) {
-        const uint32_t nn = load_row(r + 2);
+
+    auto step = [&](int r, uint32_t cur) {
+        // ---- row pass of input row r -> ring[wslot] ------------------------------------------------
         float4 tmp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (r >= 0 && r < H) { // wave-uniform
+        if (!ROW_EDGE || (r >= 0 && r < H)) {
             float4 own = make_float4((float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
                                      (float)(cur >> 24));
             *reinterpret_cast<float4 *>(rowbuf + (lane + HL) * 4) = own;
@@ -128,22 +146,24 @@ __global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
                 float acc = __fmul_rn(wv[4 * HL + j - C], t.tap[0]);
 #pragma unroll
                 for (int k = 1; k < RING; k++) acc = __fadd_rn(acc, __fmul_rn(wv[4 * HL + j - C + k], t.tap[k]));
-                res[j] = __fdiv_rn(acc, cnt_h[j]);
+                res[j] = div_by(acc, cnt_h[j], inv_h[j]);
             }
             tmp = make_float4(res[0], res[1], res[2], res[3]);
         }
         *reinterpret_cast<float4 *>(colring + wslot * 256) = tmp;
         wslot = (wslot + 1 == RING) ? 0 : wslot + 1;
 
-        const int y = r - C; // the output row whose last tap just arrived
-        if (y >= ybeg) {
-            float cnt_v = cnt_full;
-            if (y < C || y + C >= H) { // wave-uniform: top/bottom border rows renormalise
+        // ---- column pass of output row y = r - C (its last tap just arrived) -------------------------
+        const int y = r - C;
+        if (y >= ybeg && y < yend) {
+            float cnt_v = cnt_full, inv_v = inv_full;
+            if (ROW_EDGE && (y < C || y + C >= H)) { // top/bottom border rows renormalise (wave-uniform)
                 cnt_v = 0.0f;
                 for (int k = 0; k < RING; k++) {
                     int yy = y + k - C;
                     if (yy >= 0 && yy < H) cnt_v = __fadd_rn(cnt_v, t.tap[k]);
                 }
+                inv_v = __fdiv_rn(1.0f, cnt_v);
             }
             float acc[4];
 #pragma unroll
@@ -163,26 +183,116 @@ __global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
                     acc[3] = __fadd_rn(acc[3], __fmul_rn(v.w, t.tap[k]));
                 }
             }
-            oslot = (oslot + 1 == RING) ? 0 : oslot + 1;
             if (owner) {
-                int16_t o0 = (int16_t)__fdiv_rn(acc[0], cnt_v), o1 = (int16_t)__fdiv_rn(acc[1], cnt_v);
-                int16_t o2 = (int16_t)__fdiv_rn(acc[2], cnt_v), o3 = (int16_t)__fdiv_rn(acc[3], cnt_v);
-                int16_t *dst = fout + (size_t)y * W + x0;
-                if (full4) {
+                // float -> short truncates toward zero (src/utils.cpp:62)
+                const int o0 = (int)div_by(acc[0], cnt_v, inv_v), o1 = (int)div_by(acc[1], cnt_v, inv_v);
+                const int o2 = (int)div_by(acc[2], cnt_v, inv_v), o3 = (int)div_by(acc[3], cnt_v, inv_v);
+                int16_t *dst = jb.fout + (size_t)y * W + x0;
+                if (!COL_EDGE || full4) {
                     uint2 pk;
                     pk.x = (uint32_t)(uint16_t)o0 | ((uint32_t)(uint16_t)o1 << 16);
                     pk.y = (uint32_t)(uint16_t)o2 | ((uint32_t)(uint16_t)o3 << 16);
                     __builtin_memcpy(dst, &pk, 8);
                 } else {
-                    dst[0] = o0;
-                    if (x0 + 1 < W) dst[1] = o1;
-                    if (x0 + 2 < W) dst[2] = o2;
+                    dst[0] = (int16_t)o0;
+                    if (x0 + 1 < W) dst[1] = (int16_t)o1;
+                    if (x0 + 2 < W) dst[2] = (int16_t)o2;
                 }
             }
         }
-        cur = nxt;
-        nxt = nn;
+        if (y >= ybeg) oslot = (oslot + 1 == RING) ? 0 : oslot + 1;
+    };
+
+    // Rows ybeg-C .. yend-1+C, count rounded up to a multiple of 3 so that the three prefetch registers
+    // rotate by renaming (copying a register whose load is still in flight would force vmcnt(0)).
+    const int rfirst = ybeg - C;
+    const int rlast = rfirst + 3 * ((yend - 1 + C - rfirst + 3) / 3) - 1;
+    uint32_t pa = load_row(rfirst), pb = load_row(rfirst + 1), pc;
+    for (int r = rfirst; r <= rlast; r += 3) {
+        pc = load_row(r + 2);
+        step(r, pa);
+        pa = load_row(r + 3);
+        step(r + 1, pb);
+        pb = load_row(r + 4);
+        step(r + 2, pc);
     }
+}
+
+} // namespace
+
+template <int C>
+__global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
+    const uint8_t *__restrict__ img, int16_t *__restrict__ out, int H, int W, int n_strips, int n_segs, int seg_rows,
+    int total_waves, GaussTaps t)
+{
+    using K = MarchCfg<C>;
+    __shared__ __attribute__((aligned(16))) float lds[K::WPB * K::WAVE_FLOATS];
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * K::WPB + wib; // wave-uniform
+    if (wave >= total_waves) return;
+    float *rowbuf = lds + wib * K::WAVE_FLOATS;
+    float *colring = rowbuf + K::ROWBUF + lane * 4; // this lane's 4 columns, slot stride 256 floats
+
+    const int s = wave % n_strips;
+    const int g = (wave / n_strips) % n_segs;
+    const int f = wave / (n_strips * n_segs);
+    GaussJob jb;
+    jb.lane = lane;
+    jb.H = H;
+    jb.W = W;
+    jb.ybeg = g * seg_rows;
+    jb.yend = min(H, jb.ybeg + seg_rows);
+    jb.x0 = s * K::SW + (lane - K::HL) * 4; // first of this lane's 4 columns (halo lanes may be outside)
+    jb.fimg = img + (size_t)f * H * W;
+    jb.fout = out + (size_t)f * H * W;
+
+    if (lane < 4 * K::HL) { // the pads of the row buffer are only ever read by halo lanes; keep them finite
+        rowbuf[lane] = 0.0f;
+        rowbuf[(64 + K::HL) * 4 + lane] = 0.0f;
+    }
+
+    // the strip's lanes span columns [s*SW - 4HL, s*SW + SW + 4HL); taps reach C <= 4HL beyond owned columns
+    const bool col_edge = (s * K::SW - 4 * K::HL < 0) || (s * K::SW + K::SW + 4 * K::HL > W);
+    // rows touched: ybeg-C .. yend-1+C (+2 rounding, +2 prefetch)
+    const bool row_edge = (jb.ybeg - C < 0) || (jb.yend + C + 3 >= H);
+    if (col_edge) {
+        if (row_edge)
+            gauss_march_strip<C, true, true>(jb, t, rowbuf, colring);
+        else
+            gauss_march_strip<C, true, false>(jb, t, rowbuf, colring);
+    } else {
+        if (row_edge)
+            gauss_march_strip<C, false, true>(jb, t, rowbuf, colring);
+        else
+            gauss_march_strip<C, false, false>(jb, t, rowbuf, colring);
+    }
+}
+
+// ---- exhaustive check of div_by against the IEEE divide (test hook) -----------------------------------
+__global__ __launch_bounds__(256) void selftest_div_kernel(float b, unsigned first_bits, unsigned last_bits,
+                                                           unsigned long long *mismatches)
+{
+    const float y = __fdiv_rn(1.0f, b);
+    unsigned long long bad = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long u = first_bits + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= last_bits;
+         u += stride) {
+        const float a = __uint_as_float((unsigned)u);
+        const float want = __fdiv_rn(a, b);
+        const float got = div_by(a, b, y);
+        if (__float_as_uint(want) != __float_as_uint(got)) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+hipError_t launch_selftest_div(float b, unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,
+                               hipStream_t stream)
+{
+    hipLaunchKernelGGL(selftest_div_kernel, dim3(256 * 16), dim3(256), 0, stream, b, first_bits, last_bits,
+                       d_mismatches);
+    return hipGetLastError();
 }
 
 template <int C>

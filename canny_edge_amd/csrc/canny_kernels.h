@@ -81,5 +81,9 @@ hipError_t launch_fep_finalize(int16_t *cand, uint8_t *visited, const uint64_t *
 
 // ---- self-test ------------------------------------------------------------------------------
 hipError_t launch_selftest_mag_angle(int lim, int16_t *mags, uint8_t *bins, hipStream_t stream);
+// Counts floats a (bit patterns first_bits..last_bits) for which the Gaussian's reciprocal-based
+// division a/b differs from the IEEE divide; *d_mismatches must be zero beforehand.
+hipError_t launch_selftest_div(float b, unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,
+                               hipStream_t stream);
 
 } // namespace canny

@@ -14,14 +14,18 @@
 //       bin 0 iff |P| <= q, bin 90 iff |P| < -q, else 45 (P > 0) / 135   [same rule as angle_bin_d8]
 //   NMS one row later, when the magnitudes of the row below exist: strict max against the two
 //       neighbours of the bin; neighbours outside the image carry magnitude -1 (= "skip").
-// Three rows of d/t and of magnitudes rotate through registers (the row loop is unrolled by 6 so
-// that every rotation is a compile-time renaming).
+// Three rows of d/t, of magnitudes and of bin discriminants rotate through registers; the row loop is
+// unrolled by 3 so that every rotation is a compile-time renaming and the three prefetched rows never
+// have to be copied while their loads are in flight.
 //
-// Border conventions of the reference (src/utils.cpp:114-186, 248-308), all under wave-uniform branches:
+// Border conventions of the reference (src/utils.cpp:114-186, 248-308):
 //   gx: column clamp  -> zero-filled neighbours plus a +-s fix-up at columns 0 and W-1; rows dropped
 //       (virtual rows are zero, which is exactly "dropped");
 //   gy: columns dropped (zero fill), row clamp -> t[-1]:=t[0], t[H]:=t[H-1];
 //   NMS: out-of-image neighbours skipped -> magnitude -1.
+// Column borders exist only in the first and last strip: those waves run the COL_EDGE=true
+// instantiation, every other wave runs code with no lane-varying border logic at all.  Row borders are
+// wave-uniform (the wave index goes through readfirstlane) and sit behind scalar branches.
 // Precondition: smoothed values in [0,255] (what gaussian() produces), so |gx|,|gy| <= 1020.
 #include "canny_kernels.h"
 
@@ -54,98 +58,89 @@ __device__ __forceinline__ uint32_t from_right(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 
-constexpr int SNM_PX = 8;                 // pixels per lane
-constexpr int SNM_SW = 62 * SNM_PX;       // output columns per strip
-constexpr int SNM_WPB = 4;                // waves per workgroup (independent of each other)
+constexpr int SNM_PX = 8;           // pixels per lane
+constexpr int SNM_SW = 62 * SNM_PX; // output columns per strip
+constexpr int SNM_WPB = 4;          // waves per workgroup (independent of each other)
 
 template <int N>
 using IC = std::integral_constant<int, N>;
 
-} // namespace
+struct StripJob {
+    const int16_t *fin;
+    int16_t *fout;
+    int H, W, ybeg, yend, x0, lane;
+};
 
-__global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int16_t *__restrict__ in,
-                                                                       int16_t *__restrict__ out, int H, int W,
-                                                                       int n_strips, int n_segs, int seg_rows,
-                                                                       int total_waves)
+// COL_EDGE: the strip touches column 0 or W-1 (lane-varying masks, partial lanes).
+// ROW_EDGE: the segment touches row 0 or H-1 (virtual rows, row clamp).  With both false the body is
+// straight-line code with unconditional 16-byte loads, so the compiler can keep two rows of loads in
+// flight behind counted s_waitcnt vmcnt(N).
+template <bool COL_EDGE, bool ROW_EDGE>
+__device__ __forceinline__ void march_strip(const StripJob &jb)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * SNM_WPB + (threadIdx.x >> 6);
-    if (wave >= total_waves) return;
-    const int s = wave % n_strips;
-    const int g = (wave / n_strips) % n_segs;
-    const int f = wave / (n_strips * n_segs);
-    const int ybeg = g * seg_rows;
-    const int yend = min(H, ybeg + seg_rows);
-    const int x0 = s * SNM_SW + (lane - 1) * SNM_PX; // column of this lane's pixel 0
+    const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend;
     const bool full8 = x0 >= 0 && x0 + 7 < W;
-    const bool owner = lane >= 1 && lane <= 62 && x0 < W;
-    const bool first_strip = (s == 0);                                // holds column 0 (lane 1, pixel 0)
-    const bool last_strip = ((s + 1) * SNM_SW + SNM_PX >= W);          // holds column W-1 and/or columns >= W
-    const int16_t *fin = in + (size_t)f * H * W;
-    int16_t *fout = out + (size_t)f * H * W;
+    const bool owner = jb.lane >= 1 && jb.lane <= 62 && x0 < W;
 
-    // lane-varying border masks (only consulted in the first / last strip)
-    const uint32_t fix_l = (x0 == 0) ? 0x0000ffffu : 0u; // column 0 = low half of pair 0
-    uint32_t fix_r[4];
+    // lane-varying border masks (COL_EDGE only)
+    uint32_t fix_l = 0, fix_r[4] = {0, 0, 0, 0};
     unsigned oob = 0; // bit e set: column x0+e is outside the image
+    if (COL_EDGE) {
+        fix_l = (x0 == 0) ? 0x0000ffffu : 0u; // column 0 = low half of pair 0
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        uint32_t m = 0;
-        if (x0 + 2 * i == W - 1) m |= 0x0000ffffu;
-        if (x0 + 2 * i + 1 == W - 1) m |= 0xffff0000u;
-        fix_r[i] = m;
+        for (int i = 0; i < 4; i++) {
+            if (x0 + 2 * i == W - 1) fix_r[i] |= 0x0000ffffu;
+            if (x0 + 2 * i + 1 == W - 1) fix_r[i] |= 0xffff0000u;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (x0 + e < 0 || x0 + e >= W) oob |= 1u << e;
     }
-#pragma unroll
-    for (int e = 0; e < 8; e++)
-        if (x0 + e < 0 || x0 + e >= W) oob |= 1u << e;
 
     auto load_row = [&](int r, uint32_t (&p)[4]) {
-        p[0] = p[1] = p[2] = p[3] = 0u;
-        if (r < 0 || r >= H) return; // wave-uniform: virtual rows are zero
-        const int16_t *src = fin + (size_t)r * W + x0;
-        if (full8) {
+        if (ROW_EDGE && (r < 0 || r >= H)) { // wave-uniform: virtual rows are zero
+            p[0] = p[1] = p[2] = p[3] = 0u;
+            return;
+        }
+        const int16_t *src = jb.fin + (size_t)r * W + x0;
+        if (!COL_EDGE || full8) {
             uint4 v;
             __builtin_memcpy(&v, src, 16);
             p[0] = v.x;
             p[1] = v.y;
             p[2] = v.z;
             p[3] = v.w;
-        } else if (x0 + 7 >= 0 && x0 < W) {
+        } else {
+            p[0] = p[1] = p[2] = p[3] = 0u;
+            if (x0 + 7 >= 0 && x0 < W) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                int x = x0 + e;
-                if (x >= 0 && x < W) p[e >> 1] |= (uint32_t)(uint16_t)src[e] << (16 * (e & 1));
+                for (int e = 0; e < 8; e++) {
+                    int x = x0 + e;
+                    if (x >= 0 && x < W) p[e >> 1] |= (uint32_t)(uint16_t)src[e] << (16 * (e & 1));
+                }
             }
         }
     };
 
-    // rotating state (all indices are compile-time after unrolling)
-    uint32_t d[3][4], t[3][4]; // horizontal difference / smooth of three consecutive rows
-    int M[3][10];              // magnitudes of three consecutive rows; [0] and [9] are the neighbours' edge pixels
-    float cP[2][8], cQ[2][8];  // bin discriminants of the row awaiting NMS
+    // rotating state (all indices are compile-time after unrolling by 3)
+    uint32_t d[3][4], t[3][4]; // horizontal difference / smooth of rows r, r-1, r-2
+    int M[3][10];              // magnitudes of rows r-1, r-2, r-3; [0] and [9] are the neighbours' edge pixels
+    float cP[3][8], cQ[3][8];  // bin discriminants (slot of the row they belong to)
 #pragma unroll
     for (int a = 0; a < 3; a++) {
 #pragma unroll
         for (int i = 0; i < 4; i++) d[a][i] = t[a][i] = 0u;
 #pragma unroll
         for (int e = 0; e < 10; e++) M[a][e] = -1;
-    }
-#pragma unroll
-    for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int e = 0; e < 8; e++) cP[a][e] = cQ[a][e] = 0.0f;
+    }
 
-    const int rfirst = ybeg - 2, rlast = yend + 1;
-    uint32_t pa[4], pb[4], pc[4]; // software prefetch: rows r, r+1, r+2
-    load_row(rfirst, pa);
-    load_row(rfirst + 1, pb);
-
-    // One input row: PH = (r - rfirst) mod 6 selects the register roles.
+    // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
     auto step = [&](auto ph, int r, const uint32_t (&p)[4]) {
         constexpr int PH = decltype(ph)::value;
-        constexpr int k2 = PH % 3, k1 = (PH + 2) % 3, k0 = (PH + 1) % 3; // rows r, r-1, r-2 in d/t
-        constexpr int m2 = PH % 3, m1 = (PH + 2) % 3, m0 = (PH + 1) % 3; // rows r-1, r-2, r-3 in M
-        constexpr int cn = PH % 2, co = (PH + 1) % 2;                     // bins of row r-1 (new) / r-2 (old)
+        constexpr int k2 = PH % 3, k1 = (PH + 2) % 3, k0 = (PH + 1) % 3; // d/t of rows r, r-1, r-2
+        constexpr int m2 = PH % 3, m1 = (PH + 2) % 3, m0 = (PH + 1) % 3; // M and bins of rows r-1, r-2, r-3
 
         // ---- horizontal step for row r ---------------------------------------------------------
         {
@@ -161,39 +156,44 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
                 d[k2][i] = pk_sub(sh[i + 1], sh[i]);
                 t[k2][i] = pk_mad2(p[i], pk_add(sh[i], sh[i + 1]));
             }
-            if (first_strip) d[k2][0] = pk_sub(d[k2][0], p[0] & fix_l); // clamp at column 0
-            if (last_strip) {                                            // clamp at column W-1
+            if (COL_EDGE) {
+                d[k2][0] = pk_sub(d[k2][0], p[0] & fix_l); // clamp at column 0
 #pragma unroll
-                for (int i = 0; i < 4; i++) d[k2][i] = pk_add(d[k2][i], p[i] & fix_r[i]);
+                for (int i = 0; i < 4; i++) d[k2][i] = pk_add(d[k2][i], p[i] & fix_r[i]); // ... and at column W-1
             }
         }
 
         // ---- gradient, magnitude and bin discriminants for row y1 = r-1 ------------------------
         const int y1 = r - 1;
-        if (y1 >= 0 && y1 < H) {
-            uint32_t tu[4], td[4];
+        if (!ROW_EDGE || (y1 >= 0 && y1 < H)) {
+            uint32_t gy[4];
+            if (ROW_EDGE && (y1 == 0 || y1 == H - 1)) { // row clamp: t[-1] := t[0], t[H] := t[H-1]
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                tu[i] = (y1 == 0) ? t[k1][i] : t[k0][i];      // row clamp at the top
-                td[i] = (y1 == H - 1) ? t[k1][i] : t[k2][i];  // ... and at the bottom
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t tu = (y1 == 0) ? t[k1][i] : t[k0][i];
+                    const uint32_t td = (y1 == H - 1) ? t[k1][i] : t[k2][i];
+                    gy[i] = pk_sub(td, tu);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) gy[i] = pk_sub(t[k2][i], t[k0][i]);
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const uint32_t gx = pk_add(pk_mad2(d[k1][i], d[k0][i]), d[k2][i]);
-                const uint32_t gy = pk_sub(td[i], tu[i]);
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
                     const int e = 2 * i + hf;
                     const float fx = hf ? (float)((int)gx >> 16) : (float)(int)(short)(gx & 0xffffu);
-                    const float fy = hf ? (float)((int)gy >> 16) : (float)(int)(short)(gy & 0xffffu);
+                    const float fy = hf ? (float)((int)gy[i] >> 16) : (float)(int)(short)(gy[i] & 0xffffu);
                     const float A = __fmul_rn(fx, fx);
                     const float n = __fmaf_rn(fy, fy, A);
                     M[m2][e + 1] = (int)__builtin_amdgcn_sqrtf(__fadd_rn(n, 0.5f));
-                    cP[cn][e] = __fmul_rn(fx, fy);
-                    cQ[cn][e] = __fmaf_rn(n, -0.5f, A);
+                    cP[m2][e] = __fmul_rn(fx, fy);
+                    cQ[m2][e] = __fmaf_rn(n, -0.5f, A);
                 }
             }
-            if (first_strip || last_strip) { // columns outside the image never win a comparison
+            if (COL_EDGE) { // columns outside the image never win a comparison
 #pragma unroll
                 for (int e = 0; e < 8; e++)
                     if (oob & (1u << e)) M[m2][e + 1] = -1;
@@ -219,15 +219,15 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
                 const int n90 = max(M[m0][c], M[m2][c]);
                 const int n45 = max(M[m0][c + 1], M[m2][c - 1]);  // up-right, down-left
                 const int n135 = max(M[m0][c - 1], M[m2][c + 1]); // up-left, down-right
-                const float aP = __builtin_fabsf(cP[co][e]), q = cQ[co][e];
-                const int ndiag = (cP[co][e] > 0.0f) ? n45 : n135;
+                const float aP = __builtin_fabsf(cP[m1][e]), q = cQ[m1][e];
+                const int ndiag = (cP[m1][e] > 0.0f) ? n45 : n135;
                 const int nv = (aP < -q) ? n90 : ndiag;
                 const int nsel = (aP <= q) ? n0 : nv;
                 res[e] = (mc > nsel) ? mc : 0;
             }
             if (owner) {
-                int16_t *dst = fout + (size_t)y2 * W + x0;
-                if (full8) {
+                int16_t *dst = jb.fout + (size_t)y2 * W + x0;
+                if (!COL_EDGE || full8) {
                     uint4 v;
                     v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
                     v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
@@ -243,25 +243,61 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
         }
     };
 
-    for (int r = rfirst; r <= rlast; r += 6) {
-        // the prefetch registers rotate with period 3, the compute state with period 6
+    // Rows ybeg-2 .. yend+1 are needed; the count is rounded up to a multiple of 3 so that the loop
+    // body has no early exit (the extra rows produce no output: y2 >= yend).  For ROW_EDGE=false the
+    // dispatcher guarantees that even the extra rows and the two prefetched ones lie inside the image.
+    const int rfirst = ybeg - 2;
+    const int rlast = rfirst + 3 * ((yend + 1 - rfirst + 3) / 3) - 1;
+    uint32_t pa[4], pb[4], pc[4]; // software prefetch: rows r, r+1, r+2 -- renamed, never copied
+    load_row(rfirst, pa);
+    load_row(rfirst + 1, pb);
+    for (int r = rfirst; r <= rlast; r += 3) {
         load_row(r + 2, pc);
         step(IC<0>{}, r, pa);
-        if (r + 1 > rlast) break;
         load_row(r + 3, pa);
         step(IC<1>{}, r + 1, pb);
-        if (r + 2 > rlast) break;
         load_row(r + 4, pb);
         step(IC<2>{}, r + 2, pc);
-        if (r + 3 > rlast) break;
-        load_row(r + 5, pc);
-        step(IC<3>{}, r + 3, pa);
-        if (r + 4 > rlast) break;
-        load_row(r + 6, pa);
-        step(IC<4>{}, r + 4, pb);
-        if (r + 5 > rlast) break;
-        load_row(r + 7, pb);
-        step(IC<5>{}, r + 5, pc);
+    }
+}
+
+} // namespace
+
+__global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int16_t *__restrict__ in,
+                                                                       int16_t *__restrict__ out, int H, int W,
+                                                                       int n_strips, int n_segs, int seg_rows,
+                                                                       int total_waves)
+{
+    // readfirstlane tells the compiler what it cannot prove: everything derived from the wave index is
+    // wave-uniform, so rows, segments and border tests live in SGPRs and branch with s_cbranch.
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * SNM_WPB + (threadIdx.x >> 6));
+    if (wave >= total_waves) return;
+    const int s = wave % n_strips;
+    const int g = (wave / n_strips) % n_segs;
+    const int f = wave / (n_strips * n_segs);
+    StripJob jb;
+    jb.lane = threadIdx.x & 63;
+    jb.H = H;
+    jb.W = W;
+    jb.ybeg = g * seg_rows;
+    jb.yend = min(H, jb.ybeg + seg_rows);
+    jb.x0 = s * SNM_SW + (jb.lane - 1) * SNM_PX; // column of this lane's pixel 0
+    jb.fin = in + (size_t)f * H * W;
+    jb.fout = out + (size_t)f * H * W;
+    // first strip: column 0 and the out-of-image halo lane; last strip: column W-1 and columns >= W
+    const bool col_edge = (s == 0) || ((s + 1) * SNM_SW + SNM_PX >= W);
+    // rows touched: ybeg-2 .. (rounded-up last row) + 2 prefetched  <=  yend + 5
+    const bool row_edge = (jb.ybeg < 2) || (jb.yend + 5 >= H);
+    if (col_edge) {
+        if (row_edge)
+            march_strip<true, true>(jb);
+        else
+            march_strip<true, false>(jb);
+    } else {
+        if (row_edge)
+            march_strip<false, true>(jb);
+        else
+            march_strip<false, false>(jb);
     }
 }
 

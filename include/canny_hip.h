@@ -168,6 +168,9 @@ int canny_hip_profile_get(canny_hip_ctx *ctx, int stage, double *total_ms, long 
 /* Runs the DEVICE magnitude / angle-bin functions over every (gx,gy) in [-lim,lim]^2 and writes
  * tables indexed [gy+lim][gx+lim] to host memory. */
 int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes, unsigned char *bins);
+/* Compares the Gaussian kernels' reciprocal-based division a/divisor with the IEEE divide for EVERY
+ * float a in [0, 256] (1.13e9 values) on the device; *mismatches receives the number of differences. */
+int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches);
 
 #ifdef __cplusplus
 }

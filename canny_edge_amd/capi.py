@@ -107,7 +107,7 @@ def load() -> C.CDLL:
         "canny_hip_profile_reset": ([p], i),
         "canny_hip_profile_get": ([p, i, C.POINTER(C.c_double), C.POINTER(C.c_long)], i),
         "canny_hip_selftest_mag_angle": ([p, i, p, p], i),
-        "canny_hip_selftest_div": ([p, f, C.POINTER(C.c_ulonglong)], i),
+        "canny_hip_selftest_div": ([p, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -293,11 +293,12 @@ class Context:
         self._check(self._L.canny_hip_selftest_mag_angle(self._h, lim, _hp(mags), _hp(bins)), "selftest")
         return mags, bins
 
-    def selftest_div(self, divisor: float) -> int:
-        """Mismatches between the Gaussian's reciprocal division and IEEE a/divisor over all a in [0,256]."""
-        bad = C.c_ulonglong(0)
-        self._check(self._L.canny_hip_selftest_div(self._h, divisor, C.byref(bad)), "selftest_div")
-        return bad.value
+    def selftest_div(self, divisor: float) -> Tuple[int, float]:
+        """(mismatches, largest mismatching dividend) of the Gaussian's reciprocal division against IEEE
+        a/divisor over all floats a in [0,256]."""
+        bad, worst = C.c_ulonglong(0), C.c_float(0.0)
+        self._check(self._L.canny_hip_selftest_div(self._h, divisor, C.byref(bad), C.byref(worst)), "selftest_div")
+        return bad.value, worst.value
 
     # ---- device-pointer stage API (ints are device addresses; n_frames contiguous planes) -------
     def dev_gaussian(self, d_img: int, sigma: float, h: int, w: int, n: int, d_out: int):

@@ -175,7 +175,14 @@ int dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, in
     int rc = make_taps(sigma, taps);
     if (rc) return rc;
     StageTimer tm(ctx, CANNY_HIP_STAGE_GAUSSIAN);
-    const bool can_march = gaussian_march_supported(taps.center, h, w);
+    // The marching kernel divides through a precomputed reciprocal, which equals the IEEE quotient for every
+    // dividend >= 2^-102 (canny_hip_selftest_div).  Non-zero dividends are >= min_tap (row sums, pixels >= 1)
+    // and >= ~min_tap^2 (column sums), so min_tap >= 2^-48 keeps them all above 2^-97; narrower taps
+    // (sigma < ~0.13) take the generic kernels, which use the IEEE divide itself.
+    float min_tap = 1.0f;
+    for (int k = 0; k <= 2 * taps.center; k++)
+        if (taps.tap[k] > 0.0f && taps.tap[k] < min_tap) min_tap = taps.tap[k];
+    const bool can_march = gaussian_march_supported(taps.center, h, w) && min_tap >= 0x1p-48f;
     if (ctx->gaussian_path == 2 && !can_march) return CANNY_HIP_ERR_UNSUPPORTED;
     if (can_march && ctx->gaussian_path != 1) {
         HIP_TRY(ctx, launch_gaussian_march(d_img, d_out, h, w, n, taps, ctx->stream));
@@ -854,16 +861,23 @@ int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes,
     return d2h_sync(ctx, bins, ctx->io[1].p, total);
 }
 
-int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches)
+int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches,
+                           float *largest_mismatching_dividend)
 {
     int rc = bind(ctx);
     if (rc) return rc;
-    if (!mismatches || !(divisor > 0.0f) || !std::isfinite(divisor)) return CANNY_HIP_ERR_INVALID;
-    HIP_TRY(ctx, ctx->io[0].ensure(sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->io[0].p, 0, sizeof(unsigned long long), ctx->stream));
+    if (!mismatches || !largest_mismatching_dividend || !(divisor > 0.0f) || !std::isfinite(divisor))
+        return CANNY_HIP_ERR_INVALID;
+    HIP_TRY(ctx, ctx->io[0].ensure(2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io[0].p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     const unsigned last = 0x43800000u; // bit pattern of 256.0f; non-negative floats are ordered like their bits
     HIP_TRY(ctx, launch_selftest_div(divisor, 0u, last, (unsigned long long *)ctx->io[0].p, ctx->stream));
-    return d2h_sync(ctx, mismatches, ctx->io[0].p, sizeof(unsigned long long));
+    unsigned long long res[2] = {0, 0};
+    if ((rc = d2h_sync(ctx, res, ctx->io[0].p, sizeof(res)))) return rc;
+    *mismatches = res[0];
+    unsigned bits = (unsigned)res[1];
+    std::memcpy(largest_mismatching_dividend, &bits, sizeof(float));
+    return CANNY_HIP_OK;
 }
 
 } // extern "C"

@@ -275,16 +275,22 @@ __global__ __launch_bounds__(256) void selftest_div_kernel(float b, unsigned fir
                                                            unsigned long long *mismatches)
 {
     const float y = __fdiv_rn(1.0f, b);
-    unsigned long long bad = 0;
+    unsigned long long bad = 0, worst = 0;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long u = first_bits + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= last_bits;
          u += stride) {
         const float a = __uint_as_float((unsigned)u);
         const float want = __fdiv_rn(a, b);
         const float got = div_by(a, b, y);
-        if (__float_as_uint(want) != __float_as_uint(got)) bad++;
+        if (__float_as_uint(want) != __float_as_uint(got)) {
+            bad++;
+            worst = u; // u ascends within a thread
+        }
     }
-    if (bad) atomicAdd(mismatches, bad);
+    if (bad) {
+        atomicAdd(mismatches, bad);
+        atomicMax(mismatches + 1, worst); // bit pattern of the largest mismatching dividend
+    }
 }
 
 hipError_t launch_selftest_div(float b, unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,

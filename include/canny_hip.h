@@ -169,8 +169,10 @@ int canny_hip_profile_get(canny_hip_ctx *ctx, int stage, double *total_ms, long 
  * tables indexed [gy+lim][gx+lim] to host memory. */
 int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes, unsigned char *bins);
 /* Compares the Gaussian kernels' reciprocal-based division a/divisor with the IEEE divide for EVERY
- * float a in [0, 256] (1.13e9 values) on the device; *mismatches receives the number of differences. */
-int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches);
+ * float a in [0, 256] (1.13e9 values) on the device; *mismatches receives the number of differences and
+ * *largest_mismatching_dividend the largest a that differed (0 if none). */
+int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches,
+                           float *largest_mismatching_dividend);
 
 #ifdef __cplusplus
 }

@@ -43,11 +43,10 @@ struct MarchCfg {
     static constexpr int WPB = (C <= 6) ? 4 : 2;     // waves per workgroup (LDS budget)
 };
 
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
+// Orders this wave's LDS accesses in program order for the COMPILER (the hardware already executes one
+// wave's DS instructions in order).  A wavefront-scope fence emits no instruction and, unlike
+// __builtin_amdgcn_wave_barrier(), does not stop the scheduler from overlapping ALU work across it.
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 // Correctly rounded a / b given y = RN(1/b): the refinement tail of the IEEE division sequence.
 __device__ __forceinline__ float div_by(float a, float b, float y)
@@ -133,11 +132,15 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
             float wv[WIN];
 #pragma unroll
             for (int q = 0; q < WIN / 4; q++) {
-                float4 v = *reinterpret_cast<const float4 *>(rowbuf + lane * 4 + q * 4);
-                wv[4 * q + 0] = v.x;
-                wv[4 * q + 1] = v.y;
-                wv[4 * q + 2] = v.z;
-                wv[4 * q + 3] = v.w;
+                // volatile: keep each read one ds_read_b128.  Left alone the compiler narrows the reads to the
+                // elements it needs (ds_read2_b32 at a 16-byte lane stride = 4-way bank conflicts; measured:
+                // half of all LDS cycles of this kernel were SQ_LDS_BANK_CONFLICT).
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 v = *reinterpret_cast<const volatile f32x4 *>(rowbuf + lane * 4 + q * 4);
+                wv[4 * q + 0] = v[0];
+                wv[4 * q + 1] = v[1];
+                wv[4 * q + 2] = v[2];
+                wv[4 * q + 3] = v[3];
             }
             wave_lds_fence();
             float res[4];

@@ -62,7 +62,7 @@ hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, i
 // Fused Sobel+NMS, wave-marching and LDS-free (canny_sobel_nms_march.hip); smoothed must lie in [0,255].
 bool sobel_nms_march_supported(int height, int width);
 hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int tune_prefetch = 0, int tune_seg = 0);
 
 // ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
 hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,

@@ -574,22 +574,33 @@ __global__ __launch_bounds__(256) void fep_finalize_kernel(int16_t *__restrict__
 
 // Vectorised classify / finalize for widths that are a multiple of 8: one lane = 8 pixels = one
 // 16-byte load (store) and one BYTE of each bit-plane (byte k of a word holds pixels 8k..8k+7).
+// Thread i owns byte i of the tile-major planes, i.e. tile i/512, row (i%512)/8, 8-pixel group i%8:
+// a wave covers a 64-pixel x 8-row patch, reads eight 128-byte row segments and writes 64 CONTIGUOUS
+// plane bytes (byte stores at the old row-major mapping hit eight 512-byte-strided words per wave and
+// cost 4.6x write amplification in WRITE_SIZE).
+__device__ __forceinline__ bool patch_coords(const HystGeom &g, size_t i, int &f, int &y, int &x0)
+{
+    const size_t tile = i >> 9;
+    const int within = (int)(i & 511);
+    const int tpf = g.tiles_x * g.tiles_y;
+    f = (int)(tile / (size_t)tpf);
+    const int tt = (int)(tile - (size_t)f * tpf);
+    const int ty = tt / g.tiles_x, tx = tt - ty * g.tiles_x;
+    y = ty * kTile + (within >> 3);
+    x0 = tx * kTile + (within & 7) * 8;
+    return y < g.height && x0 < g.width; // width % 8 == 0: a group is entirely inside or outside
+}
+
 __global__ __launch_bounds__(256) void hyst_classify8_kernel(const int16_t *__restrict__ cand,
                                                              uint8_t *__restrict__ strong, uint8_t *__restrict__ conn,
                                                              HystGeom g, int lo, int hi, unsigned *domain_flag)
 {
-    const size_t rows_padded = (size_t)g.tiles_y * kTile;
-    const size_t groups_per_row = (size_t)g.tiles_x * 8;
-    const size_t total = (size_t)g.n_frames * rows_padded * groups_per_row;
+    const size_t total = (size_t)g.tiles() * 512;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int gx = (int)(i % groups_per_row);
-        const size_t t = i / groups_per_row;
-        const int y = (int)(t % rows_padded);
-        const int f = (int)(t / rows_padded);
-        const int x0 = gx * 8;
+        int f, y, x0;
         unsigned cbits = 0, sbits = 0;
-        if (y < g.height && x0 < g.width) { // width % 8 == 0: a group is entirely inside or outside
+        if (patch_coords(g, i, f, y, x0)) {
             uint4 v;
             __builtin_memcpy(&v, cand + ((size_t)f * g.height + y) * g.width + x0, 16);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -604,9 +615,8 @@ __global__ __launch_bounds__(256) void hyst_classify8_kernel(const int16_t *__re
             }
             if (lo <= 0 && below) atomicOr(domain_flag, 1u);
         }
-        const size_t byte = word_index(g, f, y, gx >> 3) * 8 + (gx & 7);
-        conn[byte] = (uint8_t)cbits;
-        strong[byte] = (uint8_t)sbits;
+        conn[i] = (uint8_t)cbits;
+        strong[i] = (uint8_t)sbits;
     }
 }
 
@@ -614,22 +624,19 @@ __global__ __launch_bounds__(256) void hyst_finalize8_kernel(int16_t *__restrict
                                                              const uint8_t *__restrict__ strong, HystGeom g,
                                                              int edge_value)
 {
-    const size_t groups_per_row = (size_t)(g.width / 8);
-    const size_t total = (size_t)g.n_frames * g.height * groups_per_row;
+    const size_t total = (size_t)g.tiles() * 512;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const uint32_t ev = (uint32_t)(uint16_t)edge_value;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int gx = (int)(i % groups_per_row);
-        const size_t t = i / groups_per_row;
-        const int y = (int)(t % (size_t)g.height);
-        const int f = (int)(t / (size_t)g.height);
-        const unsigned b = strong[word_index(g, f, y, gx >> 3) * 8 + (gx & 7)];
+        int f, y, x0;
+        if (!patch_coords(g, i, f, y, x0)) continue;
+        const unsigned b = strong[i];
         uint4 v;
         v.x = ((b & 1u) ? ev : 0u) | ((b & 2u) ? ev << 16 : 0u);
         v.y = ((b & 4u) ? ev : 0u) | ((b & 8u) ? ev << 16 : 0u);
         v.z = ((b & 16u) ? ev : 0u) | ((b & 32u) ? ev << 16 : 0u);
         v.w = ((b & 64u) ? ev : 0u) | ((b & 128u) ? ev << 16 : 0u);
-        __builtin_memcpy(cand + ((size_t)f * g.height + y) * g.width + (size_t)gx * 8, &v, 16);
+        __builtin_memcpy(cand + ((size_t)f * g.height + y) * g.width + x0, &v, 16);
     }
 }
 
@@ -638,7 +645,7 @@ hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t 
 {
     size_t n_words = (size_t)g.n_frames * g.tiles_y * kTile * g.tiles_x;
     if (g.width % 8 == 0)
-        hipLaunchKernelGGL(hyst_classify8_kernel, dim3(grid_for(n_words * 8, 256)), dim3(256), 0, stream, cand,
+        hipLaunchKernelGGL(hyst_classify8_kernel, dim3(grid_for((size_t)g.tiles() * 512, 256)), dim3(256), 0, stream, cand,
                            (uint8_t *)strong, (uint8_t *)conn, g, min_val, max_val, domain_flag);
     else
         hipLaunchKernelGGL(hyst_classify_kernel, dim3(grid_for(n_words * 64, 256)), dim3(256), 0, stream, cand,
@@ -658,7 +665,7 @@ hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const Hys
 {
     size_t total = (size_t)g.n_frames * g.height * g.width;
     if (g.width % 8 == 0)
-        hipLaunchKernelGGL(hyst_finalize8_kernel, dim3(grid_for(total / 8, 256)), dim3(256), 0, stream, cand,
+        hipLaunchKernelGGL(hyst_finalize8_kernel, dim3(grid_for((size_t)g.tiles() * 512, 256)), dim3(256), 0, stream, cand,
                            (const uint8_t *)strong, g, edge_value);
     else
         hipLaunchKernelGGL(hyst_finalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, cand, strong, g,

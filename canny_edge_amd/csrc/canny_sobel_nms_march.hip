@@ -41,11 +41,14 @@ __device__ __forceinline__ s16x2 as_v(uint32_t u) { return __builtin_bit_cast(s1
 __device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u(as_v(a) + as_v(b)); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u(as_v(a) - as_v(b)); }
-// a*2 + b per half
+// a*2 + b per half as ONE v_pk_mad_i16 (hipcc otherwise emits v_pk_mul_lo_u16 / v_pk_lshlrev_b16 plus
+// an add; this kernel is VALU-issue bound, so every instruction per pixel counts).
 __device__ __forceinline__ uint32_t pk_mad2(uint32_t a, uint32_t b)
 {
-    const s16x2 two = {2, 2};
-    return as_u(as_v(a) * two + as_v(b));
+    uint32_t r;
+    const uint32_t two = 0x00020002u;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(two), "v"(b));
+    return r;
 }
 
 // value held by the lane to the left / right (0 at the wave's ends)
@@ -186,11 +189,13 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
                     const int e = 2 * i + hf;
                     const float fx = hf ? (float)((int)gx >> 16) : (float)(int)(short)(gx & 0xffffu);
                     const float fy = hf ? (float)((int)gy[i] >> 16) : (float)(int)(short)(gy[i] & 0xffffu);
-                    const float A = __fmul_rn(fx, fx);
-                    const float n = __fmaf_rn(fy, fy, A);
-                    M[m2][e + 1] = (int)__builtin_amdgcn_sqrtf(__fadd_rn(n, 0.5f));
+                    // all exact in f32 (integers and halves below 2^24):
+                    //   Ah = gx^2 + 1/2,  nh = gx^2 + gy^2 + 1/2,  P = gx*gy,  Q = Ah - nh/2 = (gx^2-gy^2)/2 + 1/4
+                    const float Ah = __fmaf_rn(fx, fx, 0.5f);
+                    const float nh = __fmaf_rn(fy, fy, Ah);
+                    M[m2][e + 1] = (int)__builtin_amdgcn_sqrtf(nh); // floor(sqrt(n)), see magnitude_d8
                     cP[m2][e] = __fmul_rn(fx, fy);
-                    cQ[m2][e] = __fmaf_rn(n, -0.5f, A);
+                    cQ[m2][e] = __fmaf_rn(nh, -0.5f, Ah);
                 }
             }
             if (COL_EDGE) { // columns outside the image never win a comparison
@@ -219,10 +224,16 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
                 const int n90 = max(M[m0][c], M[m2][c]);
                 const int n45 = max(M[m0][c + 1], M[m2][c - 1]);  // up-right, down-left
                 const int n135 = max(M[m0][c - 1], M[m2][c + 1]); // up-left, down-right
-                const float aP = __builtin_fabsf(cP[m1][e]), q = cQ[m1][e];
-                const int ndiag = (cP[m1][e] > 0.0f) ? n45 : n135;
-                const int nv = (aP < -q) ? n90 : ndiag;
-                const int nsel = (aP <= q) ? n0 : nv;
+                // Bin from two sign tests.  With X = gx^2-gy^2 and Y = 2 gx gy (the doubled angle) the bins are
+                // the quadrants of (X+Y, X-Y):  0: both >= 0,  90: both < 0,  45: X+Y >= 0 > X-Y,  135: the rest.
+                // P and X/2 are multiples of 1/2 and Q = X/2 + 1/4, so  X-Y >= 0  <=>  P <= Q  and
+                // X+Y >= 0  <=>  P > -Q  exactly (same rule as angle_bin_d8, checked exhaustively on the device).
+                const float P = cP[m1][e], Q = cQ[m1][e];
+                const bool v_ge0 = P <= Q;  // X - Y >= 0
+                const bool u_ge0 = P > -Q;  // X + Y >= 0
+                const int na = v_ge0 ? n0 : n45;
+                const int nb = v_ge0 ? n135 : n90;
+                const int nsel = u_ge0 ? na : nb;
                 res[e] = (mc > nsel) ? mc : 0;
             }
             if (owner) {
@@ -303,12 +314,16 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
 
 bool sobel_nms_march_supported(int height, int width) { return height >= 2 && width >= 2; }
 
+// tune_seg: 0 = automatic, else rows per segment (A/B knob).  tune_prefetch is accepted for ABI stability of
+// the option and ignored: a 5-row prefetch distance measured identical to 2 rows (the kernel is VALU bound).
 hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
-                                  hipStream_t stream)
+                                  hipStream_t stream, int tune_prefetch, int tune_seg)
 {
+    (void)tune_prefetch;
     int n_strips = (width + SNM_SW - 1) / SNM_SW;
     int seg = 256;
     while (seg > 32 && (long long)n_frames * n_strips * ((height + seg - 1) / seg) < 16384) seg >>= 1;
+    if (tune_seg >= 8) seg = tune_seg;
     int n_segs = (height + seg - 1) / seg;
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;

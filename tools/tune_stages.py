@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""A/B timing of individual stages in ONE process with interleaved rounds (cdna guide rule 24).
+
+    python tools/tune_stages.py [--frames 64] [--rounds 5]
+
+Prints the median / min device time (HIP events on the launch stream) of the fused Sobel+NMS kernel for
+each tuning configuration, plus the other stages of the pipeline for reference."""
+import argparse
+import statistics
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+
+from canny_edge_amd import capi
+from canny_edge_amd.synth import synth_frame
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--sigma", type=float, default=1.4)
+    args = ap.parse_args()
+    H, W, F = args.height, args.width, args.frames
+    ctx = capi.Context(0)
+    base = np.stack([synth_frame(H, W, 42 + i) for i in range(min(8, F))])
+    d_img = ctx.malloc(F * H * W)
+    for i in range(F):
+        ctx.h2d(d_img + i * H * W, base[i % len(base)])
+    d_sm = ctx.malloc(F * H * W * 2)
+    d_out = ctx.malloc(F * H * W * 2)
+    ctx.dev_gaussian(d_img, args.sigma, H, W, F, d_sm)
+    ctx.synchronize()
+    ctx.profile_enable(True)
+
+    def time_stage(fn, stage):
+        ctx.profile_reset()
+        fn()
+        ms, n = ctx.profile_get(stage)
+        return ms / max(n, 1)
+
+    configs = [("pf2_segauto", 2, 0), ("pf5_segauto", 5, 0), ("pf2_seg32", 2, 32), ("pf2_seg48", 2, 48),
+               ("pf2_seg64", 2, 64), ("pf2_seg90", 2, 90), ("pf2_seg120", 2, 120), ("pf2_seg180", 2, 180),
+               ("pf2_seg360", 2, 360), ("pf5_seg360", 5, 360), ("pf2_seg270", 2, 270), ("pf2_seg216", 2, 216)]
+    res = {name: [] for name, _, _ in configs}
+    for _ in range(args.rounds):
+        for name, pf, seg in configs:
+            ctx.set_option("tune_sobel_prefetch", pf)
+            ctx.set_option("tune_sobel_seg", seg)
+            res[name].append(time_stage(lambda: ctx.dev_sobel_nms(d_sm, H, W, F, d_out), capi.STAGE_SOBEL_NMS))
+    alg = 4.0 * F * H * W
+    print(f"fused Sobel+NMS, {F} x {W}x{H}, algorithmic {alg / 1e9:.3f} GB per launch")
+    for name, _, _ in configs:
+        v = res[name]
+        med, mn = statistics.median(v), min(v)
+        print(f"  {name:14s} median {med:.4f} ms  min {mn:.4f} ms   {alg / med / 1e6:.0f} GB/s  ({alg / med / 8e9 * 100:.1f}% of 8 TB/s)")
+    ctx.set_option("tune_sobel_prefetch", 0)
+    ctx.set_option("tune_sobel_seg", 0)
+
+    g = [time_stage(lambda: ctx.dev_gaussian(d_img, args.sigma, H, W, F, d_sm), capi.STAGE_GAUSSIAN)
+         for _ in range(args.rounds)]
+    print(f"gaussian march   median {statistics.median(g):.4f} ms  min {min(g):.4f} ms")
+    ctx.dev_sobel_nms(d_sm, H, W, F, d_out)
+    hy = {"hyst_classify": [], "hyst_propagate": [], "hyst_finalize": []}
+    for _ in range(args.rounds):
+        ctx.dev_sobel_nms(d_sm, H, W, F, d_out)
+        ctx.profile_reset()
+        ctx.dev_hysteresis(d_out, H, W, F, 50, 150)
+        for k, sid in (("hyst_classify", 2), ("hyst_propagate", 3), ("hyst_finalize", 4)):
+            ms, n = ctx.profile_get(sid)
+            hy[k].append(ms)
+    for k, v in hy.items():
+        print(f"{k:16s} median {statistics.median(v):.4f} ms  min {min(v):.4f} ms")
+    print("hysteresis sweeps:", ctx.last_hysteresis_iterations)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

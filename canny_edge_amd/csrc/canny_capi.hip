@@ -198,7 +198,7 @@ int ensure_hyst(canny_hip_ctx *ctx, const HystGeom &g)
 {
     HIP_TRY(ctx, ctx->plane_s.ensure(g.words() * sizeof(uint64_t)));
     HIP_TRY(ctx, ctx->plane_c.ensure(g.words() * sizeof(uint64_t)));
-    HIP_TRY(ctx, ctx->stamps.ensure((size_t)g.tiles() * sizeof(unsigned)));
+    HIP_TRY(ctx, ctx->stamps.ensure(hyst_sched_words(g) * sizeof(unsigned)));
     HIP_TRY(ctx, ctx->flags.ensure(2 * sizeof(unsigned)));
     if (!ctx->host_flags) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->host_flags, 2 * sizeof(unsigned)));
     return CANNY_HIP_OK;
@@ -209,8 +209,9 @@ int run_propagation(canny_hip_ctx *ctx, const HystGeom &g)
 {
     uint64_t *S = (uint64_t *)ctx->plane_s.p;
     const uint64_t *C = (const uint64_t *)ctx->plane_c.p;
-    unsigned *stamp = (unsigned *)ctx->stamps.p;
+    unsigned *stamp = (unsigned *)ctx->stamps.p; // tile stamps + work queues + queue counters
     unsigned *flags = (unsigned *)ctx->flags.p;
+    HIP_TRY(ctx, hipMemsetAsync(stamp, 0, hyst_sched_words(g) * sizeof(unsigned), ctx->stream));
     const int kMaxSweeps = 1 << 22;
     int iter = 0;
     for (;;) {

@@ -132,11 +132,12 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
             float wv[WIN];
 #pragma unroll
             for (int q = 0; q < WIN / 4; q++) {
-                // volatile: keep each read one ds_read_b128.  Left alone the compiler narrows the reads to the
-                // elements it needs (ds_read2_b32 at a 16-byte lane stride = 4-way bank conflicts; measured:
-                // half of all LDS cycles of this kernel were SQ_LDS_BANK_CONFLICT).
+                // Not volatile on purpose.  The compiler narrows these reads to the elements it needs
+                // (ds_read2_b32 at a 16-byte lane stride: 4-way bank conflicts, half of this kernel's LDS
+                // cycles), but forcing five full ds_read_b128 measured 20 % SLOWER (1.16 vs 0.93 ms per
+                // 64 x 4K): the kernel is VALU bound and the wider reads only add LDS traffic and waits.
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
-                const f32x4 v = *reinterpret_cast<const volatile f32x4 *>(rowbuf + lane * 4 + q * 4);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(rowbuf + lane * 4 + q * 4);
                 wv[4 * q + 0] = v[0];
                 wv[4 * q + 1] = v[1];
                 wv[4 * q + 2] = v[2];

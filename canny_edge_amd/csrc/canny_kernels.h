@@ -67,9 +67,10 @@ hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int hei
 // ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
 hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,
                                 int max_val, unsigned *domain_flag, hipStream_t stream);
-// One propagation sweep (`iter` = 0,1,2,...).  stamp has g.tiles() entries; last_change is one word
-// that must be zero before iteration 0.
-hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *stamp, unsigned *last_change,
+// One propagation sweep (`iter` = 0,1,2,...).  sched holds hyst_sched_words(g) words (tile stamps, two
+// work queues, three queue counters) and, like the single word last_change, must be zero before sweep 0.
+inline size_t hyst_sched_words(const HystGeom &g) { return 3 * (size_t)g.tiles() + 4; }
+hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
                                  int iter, const HystGeom &g, hipStream_t stream);
 hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const HystGeom &g, int edge_value,
                                 hipStream_t stream);

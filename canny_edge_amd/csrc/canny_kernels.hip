@@ -400,18 +400,41 @@ __global__ __launch_bounds__(256) void hyst_classify_kernel(const int16_t *__res
     }
 }
 
-__global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restrict__ strong,
-                                                             const uint64_t *__restrict__ conn,
-                                                             unsigned *__restrict__ stamp,
-                                                             unsigned *__restrict__ last_change, int iter, HystGeom g)
+// row above / below (lane = row) through wave-wide DPP shifts; the wave's end lanes read 0
+__device__ __forceinline__ uint64_t row_above_u64(uint64_t v)
 {
-    // Nothing was scheduled for this sweep: the whole grid drains immediately.
-    if (iter > 0 && __hip_atomic_load(last_change, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)iter) return;
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= g.tiles()) return;
-    if (iter > 0 && stamp[t] != (unsigned)iter) return;
+    unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, true);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t row_below_u64(uint64_t v)
+{
+    unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), 0x130, 0xf, 0xf, true);
+    return ((uint64_t)hi << 32) | lo;
+}
 
+// Scheduling words of one hysteresis call (all zero before sweep 0):
+//   stamp[tiles]    sweep at which a tile was last queued (dedupes pushes within a sweep)
+//   queue[2][tiles] tiles to run in sweep k are queue[k & 1][0 .. count[k % 3])
+//   count[3]        sweep k reads count[k%3], appends to count[(k+1)%3] and clears count[(k+2)%3]
+struct HystSched {
+    unsigned *stamp, *queue0, *queue1, *count;
+};
+__device__ __forceinline__ HystSched make_sched(unsigned *words, int tiles)
+{
+    HystSched s;
+    s.stamp = words;
+    s.queue0 = words + tiles;
+    s.queue1 = words + 2 * (size_t)tiles;
+    s.count = words + 3 * (size_t)tiles;
+    return s;
+}
+
+__device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__restrict__ strong,
+                                               const uint64_t *__restrict__ conn, const HystSched &sch,
+                                               unsigned *__restrict__ last_change, int iter, const HystGeom &g)
+{
     const int tpf = g.tiles_x * g.tiles_y;
     const int tt = t % tpf;
     const int ty = tt / g.tiles_x, tx = tt - ty * g.tiles_x;
@@ -442,7 +465,7 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
 
     uint64_t s = s0;
     for (;;) {
-        uint64_t up = shfl_up_u64(s), dn = shfl_down_u64(s);
+        uint64_t up = row_above_u64(s), dn = row_below_u64(s);
         if (lane == 0) up = su;
         if (lane == 63) dn = sd;
         uint64_t d = up | s | dn;
@@ -476,19 +499,50 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
         const uint64_t bot = lane_u64(chg, 63);   // ... and in its last row
         const bool anyL = __any((chg & 1ull) != 0), anyR = __any((chg >> 63) != 0);
         if (lane == 0) {
+            // queue every neighbour whose facing border changed for the next sweep (once per sweep)
             const unsigned nxt = (unsigned)iter + 1u;
+            unsigned *q = (nxt & 1u) ? sch.queue1 : sch.queue0;
+            unsigned *cnt = sch.count + nxt % 3u;
             bool marked = false;
-            if (hasU && top64) { stamp[t - g.tiles_x] = nxt; marked = true; }
-            if (hasD && bot) { stamp[t + g.tiles_x] = nxt; marked = true; }
-            if (hasL && anyL) { stamp[t - 1] = nxt; marked = true; }
-            if (hasR && anyR) { stamp[t + 1] = nxt; marked = true; }
-            if (hasU && hasL && (top64 & 1ull)) { stamp[t - g.tiles_x - 1] = nxt; marked = true; }
-            if (hasU && hasR && (top64 >> 63)) { stamp[t - g.tiles_x + 1] = nxt; marked = true; }
-            if (hasD && hasL && (bot & 1ull)) { stamp[t + g.tiles_x - 1] = nxt; marked = true; }
-            if (hasD && hasR && (bot >> 63)) { stamp[t + g.tiles_x + 1] = nxt; marked = true; }
+            auto push = [&](int nb) {
+                if (atomicExch(&sch.stamp[nb], nxt) != nxt) q[atomicAdd(cnt, 1u)] = (unsigned)nb;
+                marked = true;
+            };
+            if (hasU && top64) push(t - g.tiles_x);
+            if (hasD && bot) push(t + g.tiles_x);
+            if (hasL && anyL) push(t - 1);
+            if (hasR && anyR) push(t + 1);
+            if (hasU && hasL && (top64 & 1ull)) push(t - g.tiles_x - 1);
+            if (hasU && hasR && (top64 >> 63)) push(t - g.tiles_x + 1);
+            if (hasD && hasL && (bot & 1ull)) push(t + g.tiles_x - 1);
+            if (hasD && hasR && (bot >> 63)) push(t + g.tiles_x + 1);
             if (marked) atomicMax(last_change, nxt);
         }
     }
+}
+
+// Sweep 0 visits every tile (grid = tiles/4 workgroups); later sweeps are launched with a small fixed
+// grid whose waves walk the work queue, so a sweep with little or nothing to do costs one short launch
+// instead of 130 k waves that each read a stamp and exit.
+__global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restrict__ strong,
+                                                             const uint64_t *__restrict__ conn,
+                                                             unsigned *__restrict__ sched_words,
+                                                             unsigned *__restrict__ last_change, int iter, HystGeom g)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int n_waves = gridDim.x * 4;
+    const int tiles = g.tiles();
+    const HystSched sch = make_sched(sched_words, tiles);
+    if (wave == 0 && lane == 0) sch.count[(iter + 2) % 3] = 0; // the slot sweep iter+1 will append to
+    if (iter == 0) {
+        for (int t = wave; t < tiles; t += n_waves) propagate_tile(t, lane, strong, conn, sch, last_change, iter, g);
+        return;
+    }
+    const unsigned n = __hip_atomic_load(sch.count + iter % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned *q = (iter & 1) ? sch.queue1 : sch.queue0;
+    for (unsigned i = (unsigned)wave; i < n; i += (unsigned)n_waves)
+        propagate_tile((int)q[i], lane, strong, conn, sch, last_change, iter, g);
 }
 
 __global__ __launch_bounds__(256) void hyst_finalize_kernel(int16_t *__restrict__ cand,
@@ -572,6 +626,14 @@ __global__ __launch_bounds__(256) void fep_finalize_kernel(int16_t *__restrict__
     }
 }
 
+// saturating per-half a - b: the sign of each half is the sign of the true difference for any shorts
+__device__ __forceinline__ uint32_t pk_sub_sat_i16(uint32_t a, uint32_t b)
+{
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, a),
+                                                                      __builtin_bit_cast(s16x2_t, b)));
+}
+
 // Vectorised classify / finalize for widths that are a multiple of 8: one lane = 8 pixels = one
 // 16-byte load (store) and one BYTE of each bit-plane (byte k of a word holds pixels 8k..8k+7).
 // Thread i owns byte i of the tile-major planes, i.e. tile i/512, row (i%512)/8, 8-pixel group i%8:
@@ -597,6 +659,8 @@ __global__ __launch_bounds__(256) void hyst_classify8_kernel(const int16_t *__re
 {
     const size_t total = (size_t)g.tiles() * 512;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const bool fast = lo >= -32768 && lo <= 32767 && hi >= -32768 && hi <= 32767; // wave-uniform
+    const uint32_t lo2 = ((uint32_t)lo & 0xffffu) * 0x10001u, hi2 = ((uint32_t)hi & 0xffffu) * 0x10001u;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         int f, y, x0;
         unsigned cbits = 0, sbits = 0;
@@ -604,16 +668,40 @@ __global__ __launch_bounds__(256) void hyst_classify8_kernel(const int16_t *__re
             uint4 v;
             __builtin_memcpy(&v, cand + ((size_t)f * g.height + y) * g.width + x0, 16);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            bool below = false;
+            if (fast) {
+                // Packed path (thresholds fit a short): 4.3 VALU ops per pixel instead of 18.7.
+                // Regroup so that the low halves hold pixels 0..3 and the high halves pixels 4..7; a
+                // saturating packed subtract leaves the sign bit of each half clear iff px >= threshold;
+                // shifting register k right by 3-k lines the eight sign bits up as two nibbles.
+                const uint32_t r[4] = {__builtin_amdgcn_perm(w[2], w[0], 0x05040100u),  // (px0, px4)
+                                       __builtin_amdgcn_perm(w[2], w[0], 0x07060302u),  // (px1, px5)
+                                       __builtin_amdgcn_perm(w[3], w[1], 0x05040100u),  // (px2, px6)
+                                       __builtin_amdgcn_perm(w[3], w[1], 0x07060302u)}; // (px3, px7)
+                uint32_t dc[4], ds[4];
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int px = (e & 1) ? ((int)w[e >> 1] >> 16) : (int)(short)(w[e >> 1] & 0xffffu);
-                const bool c = px >= lo;
-                cbits |= (unsigned)c << e;
-                sbits |= (unsigned)(c && px >= hi) << e;
-                below |= px < lo;
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t a = pk_sub_sat_i16(r[k], lo2); // sign set  <=>  px <  lo
+                    const uint32_t b = pk_sub_sat_i16(r[k], hi2); // sign set  <=>  px <  hi
+                    dc[k] = a & 0x80008000u;
+                    ds[k] = (a | b) & 0x80008000u;
+                }
+                const uint32_t xc = (dc[0] >> 3) | (dc[1] >> 2) | (dc[2] >> 1) | dc[3];
+                const uint32_t xs = (ds[0] >> 3) | (ds[1] >> 2) | (ds[2] >> 1) | ds[3];
+                cbits = (((xc >> 12) & 0xfu) | ((xc >> 24) & 0xf0u)) ^ 0xffu;
+                sbits = (((xs >> 12) & 0xfu) | ((xs >> 24) & 0xf0u)) ^ 0xffu;
+                if (lo <= 0 && cbits != 0xffu) atomicOr(domain_flag, 1u);
+            } else {
+                bool below = false;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int px = (e & 1) ? ((int)w[e >> 1] >> 16) : (int)(short)(w[e >> 1] & 0xffffu);
+                    const bool c = px >= lo;
+                    cbits |= (unsigned)c << e;
+                    sbits |= (unsigned)(c && px >= hi) << e;
+                    below |= px < lo;
+                }
+                if (lo <= 0 && below) atomicOr(domain_flag, 1u);
             }
-            if (lo <= 0 && below) atomicOr(domain_flag, 1u);
         }
         conn[i] = (uint8_t)cbits;
         strong[i] = (uint8_t)sbits;
@@ -631,11 +719,13 @@ __global__ __launch_bounds__(256) void hyst_finalize8_kernel(int16_t *__restrict
         int f, y, x0;
         if (!patch_coords(g, i, f, y, x0)) continue;
         const unsigned b = strong[i];
+        // bit 2k -> bit 0 and bit 2k+1 -> bit 16 of register k, then one 24-bit multiply by the edge value
+        const uint32_t t = b | (b << 15);
         uint4 v;
-        v.x = ((b & 1u) ? ev : 0u) | ((b & 2u) ? ev << 16 : 0u);
-        v.y = ((b & 4u) ? ev : 0u) | ((b & 8u) ? ev << 16 : 0u);
-        v.z = ((b & 16u) ? ev : 0u) | ((b & 32u) ? ev << 16 : 0u);
-        v.w = ((b & 64u) ? ev : 0u) | ((b & 128u) ? ev << 16 : 0u);
+        v.x = __umul24(t & 0x00010001u, ev);
+        v.y = __umul24((t >> 2) & 0x00010001u, ev);
+        v.z = __umul24((t >> 4) & 0x00010001u, ev);
+        v.w = __umul24((t >> 6) & 0x00010001u, ev);
         __builtin_memcpy(cand + ((size_t)f * g.height + y) * g.width + x0, &v, 16);
     }
 }
@@ -656,6 +746,7 @@ hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigne
                                  int iter, const HystGeom &g, hipStream_t stream)
 {
     unsigned blocks = (unsigned)((g.tiles() + 3) / 4);
+    if (iter > 0 && blocks > 1024u) blocks = 1024u; // queue walkers: 16 waves per CU
     hipLaunchKernelGGL(hyst_propagate_kernel, dim3(blocks), dim3(256), 0, stream, strong, conn, stamp, last_change,
                        iter, g);
     return hipGetLastError();

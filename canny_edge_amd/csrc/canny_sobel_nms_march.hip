@@ -52,13 +52,21 @@ __device__ __forceinline__ uint32_t pk_mad2(uint32_t a, uint32_t b)
 }
 
 // value held by the lane to the left / right (0 at the wave's ends)
+// bound_ctrl: a lane whose source lies outside the wave reads 0, so no `old` value has to be
+// materialised (with update_dpp(0, ...) every shift cost an extra v_mov_b32 v, 0).
 __device__ __forceinline__ uint32_t from_left(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t from_right(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+// two non-negative ints (< 65536) -> packed u16 pair, one v_cvt_pk_u16_u32
+__device__ __forceinline__ uint32_t pack_u16(int lo, int hi)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (u16x2)__builtin_amdgcn_cvt_pk_u16((unsigned)lo, (unsigned)hi));
 }
 
 constexpr int SNM_PX = 8;           // pixels per lane
@@ -240,10 +248,10 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
                 int16_t *dst = jb.fout + (size_t)y2 * W + x0;
                 if (!COL_EDGE || full8) {
                     uint4 v;
-                    v.x = (uint32_t)res[0] | ((uint32_t)res[1] << 16);
-                    v.y = (uint32_t)res[2] | ((uint32_t)res[3] << 16);
-                    v.z = (uint32_t)res[4] | ((uint32_t)res[5] << 16);
-                    v.w = (uint32_t)res[6] | ((uint32_t)res[7] << 16);
+                    v.x = pack_u16(res[0], res[1]);
+                    v.y = pack_u16(res[2], res[3]);
+                    v.z = pack_u16(res[4], res[5]);
+                    v.w = pack_u16(res[6], res[7]);
                     __builtin_memcpy(dst, &v, 16);
                 } else {
 #pragma unroll

@@ -640,14 +640,15 @@ __device__ __forceinline__ uint32_t pk_sub_sat_i16(uint32_t a, uint32_t b)
 // a wave covers a 64-pixel x 8-row patch, reads eight 128-byte row segments and writes 64 CONTIGUOUS
 // plane bytes (byte stores at the old row-major mapping hit eight 512-byte-strided words per wave and
 // cost 4.6x write amplification in WRITE_SIZE).
-__device__ __forceinline__ bool patch_coords(const HystGeom &g, size_t i, int &f, int &y, int &x0)
+// Launched on a 3-D grid (2*tiles_x, tiles_y, n_frames) of 256-thread workgroups: a workgroup is half a
+// tile (32 rows), so no thread ever divides (a flat index needed two 64-bit divisions per thread, which was
+// most of these kernels' VALU time).
+__device__ __forceinline__ bool patch_coords(const HystGeom &g, size_t &i, int &f, int &y, int &x0)
 {
-    const size_t tile = i >> 9;
-    const int within = (int)(i & 511);
-    const int tpf = g.tiles_x * g.tiles_y;
-    f = (int)(tile / (size_t)tpf);
-    const int tt = (int)(tile - (size_t)f * tpf);
-    const int ty = tt / g.tiles_x, tx = tt - ty * g.tiles_x;
+    const int tx = (int)(blockIdx.x >> 1), ty = (int)blockIdx.y;
+    const int within = (int)((blockIdx.x & 1u) * 256u + threadIdx.x);
+    f = (int)blockIdx.z;
+    i = ((((size_t)f * g.tiles_y + ty) * g.tiles_x + tx) << 9) + within;
     y = ty * kTile + (within >> 3);
     x0 = tx * kTile + (within & 7) * 8;
     return y < g.height && x0 < g.width; // width % 8 == 0: a group is entirely inside or outside
@@ -657,12 +658,11 @@ __global__ __launch_bounds__(256) void hyst_classify8_kernel(const int16_t *__re
                                                              uint8_t *__restrict__ strong, uint8_t *__restrict__ conn,
                                                              HystGeom g, int lo, int hi, unsigned *domain_flag)
 {
-    const size_t total = (size_t)g.tiles() * 512;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
     const bool fast = lo >= -32768 && lo <= 32767 && hi >= -32768 && hi <= 32767; // wave-uniform
     const uint32_t lo2 = ((uint32_t)lo & 0xffffu) * 0x10001u, hi2 = ((uint32_t)hi & 0xffffu) * 0x10001u;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    {
         int f, y, x0;
+        size_t i;
         unsigned cbits = 0, sbits = 0;
         if (patch_coords(g, i, f, y, x0)) {
             uint4 v;
@@ -712,12 +712,11 @@ __global__ __launch_bounds__(256) void hyst_finalize8_kernel(int16_t *__restrict
                                                              const uint8_t *__restrict__ strong, HystGeom g,
                                                              int edge_value)
 {
-    const size_t total = (size_t)g.tiles() * 512;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
     const uint32_t ev = (uint32_t)(uint16_t)edge_value;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    {
         int f, y, x0;
-        if (!patch_coords(g, i, f, y, x0)) continue;
+        size_t i;
+        if (!patch_coords(g, i, f, y, x0)) return;
         const unsigned b = strong[i];
         // bit 2k -> bit 0 and bit 2k+1 -> bit 16 of register k, then one 24-bit multiply by the edge value
         const uint32_t t = b | (b << 15);
@@ -735,8 +734,8 @@ hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t 
 {
     size_t n_words = (size_t)g.n_frames * g.tiles_y * kTile * g.tiles_x;
     if (g.width % 8 == 0)
-        hipLaunchKernelGGL(hyst_classify8_kernel, dim3(grid_for((size_t)g.tiles() * 512, 256)), dim3(256), 0, stream, cand,
-                           (uint8_t *)strong, (uint8_t *)conn, g, min_val, max_val, domain_flag);
+        hipLaunchKernelGGL(hyst_classify8_kernel, dim3(2 * g.tiles_x, g.tiles_y, g.n_frames), dim3(256), 0, stream,
+                           cand, (uint8_t *)strong, (uint8_t *)conn, g, min_val, max_val, domain_flag);
     else
         hipLaunchKernelGGL(hyst_classify_kernel, dim3(grid_for(n_words * 64, 256)), dim3(256), 0, stream, cand,
                            strong, conn, g, min_val, max_val, domain_flag);
@@ -756,7 +755,7 @@ hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const Hys
 {
     size_t total = (size_t)g.n_frames * g.height * g.width;
     if (g.width % 8 == 0)
-        hipLaunchKernelGGL(hyst_finalize8_kernel, dim3(grid_for((size_t)g.tiles() * 512, 256)), dim3(256), 0, stream, cand,
+        hipLaunchKernelGGL(hyst_finalize8_kernel, dim3(2 * g.tiles_x, g.tiles_y, g.n_frames), dim3(256), 0, stream, cand,
                            (const uint8_t *)strong, g, edge_value);
     else
         hipLaunchKernelGGL(hyst_finalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, cand, strong, g,

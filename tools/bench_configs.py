@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Times the other BASELINE.json configurations (they are parity-test cases, not the headline bench line):
+
+  C2  single 3840x2160 frame, sigma 1.4   -- device-resident latency and host-to-host latency
+  C3  batch of N x 1080p frames, sigma 1.0 -- canny_hip_canny_batch: host u8 in -> host s16 out, PCIe included,
+                                               H2D / kernels / D2H overlapped on three streams
+  C4  single 16384x16384 tile, sigma 2.0   -- device-resident and host-to-host
+
+Prints one JSON object.  `python tools/bench_configs.py [--c3-frames 1024]`"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+
+from canny_edge_amd import capi
+from canny_edge_amd.synth import synth_frame
+
+
+def timed(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c3-frames", type=int, default=1024)
+    ap.add_argument("--skip-c4", action="store_true")
+    args = ap.parse_args()
+    out = {}
+    ctx = capi.Context(0)
+
+    # ---- C2: one 4K frame ------------------------------------------------------------------------
+    H, W = 2160, 3840
+    img = synth_frame(H, W, 42)
+    d_in, d_out = ctx.malloc(img.nbytes), ctx.malloc(img.nbytes * 2)
+    ctx.h2d(d_in, img)
+
+    def dev_once():
+        ctx.dev_canny(d_in, 1.4, 50, 150, H, W, 1, d_out)
+        ctx.synchronize()
+    t_dev = timed(dev_once, 20)
+    t_host = timed(lambda: ctx.canny(img, 1.4, 50, 150), 5)
+    out["C2_single_4k_sigma1.4"] = {
+        "device_resident_ms": round(t_dev * 1e3, 4), "device_resident_Mpix_s": round(H * W / t_dev / 1e6, 1),
+        "host_to_host_ms": round(t_host * 1e3, 3), "host_to_host_Mpix_s": round(H * W / t_host / 1e6, 1),
+        "hysteresis_sweeps": ctx.last_hysteresis_iterations}
+    ctx.free(d_in)
+    ctx.free(d_out)
+
+    # ---- C3: batch of 1080p frames through the stream-overlapped host API ---------------------------
+    H, W, N = 1080, 1920, args.c3_frames
+    base = np.stack([synth_frame(H, W, 100 + i) for i in range(16)])
+    frames = np.empty((N, H, W), np.uint8)
+    for i in range(N):
+        frames[i] = base[i % 16]
+    ctx.canny_batch(frames[:32], 1.0, 50, 150)  # warm-up (pinned staging, module load)
+    t0 = time.perf_counter()
+    edges = ctx.canny_batch(frames, 1.0, 50, 150)
+    t = time.perf_counter() - t0
+    out["C3_batch_1080p_sigma1.0"] = {
+        "frames": N, "seconds": round(t, 4), "Mpix_s_pcie_inclusive": round(N * H * W / t / 1e6, 1),
+        "GB_moved": round((frames.nbytes + edges.nbytes) / 1e9, 2),
+        "edge_fraction": round(float(np.count_nonzero(edges[:16])) / edges[:16].size, 5)}
+    del frames, edges
+
+    # ---- C4: one 16384 x 16384 tile ---------------------------------------------------------------------
+    if not args.skip_c4:
+        H = W = 16384
+        img = np.tile(synth_frame(2048, 2048, 7), (8, 8))
+        d_in, d_out = ctx.malloc(img.nbytes), ctx.malloc(img.nbytes * 2)
+        ctx.h2d(d_in, img)
+
+        def dev16():
+            ctx.dev_canny(d_in, 2.0, 50, 150, H, W, 1, d_out)
+            ctx.synchronize()
+        t_dev = timed(dev16, 5)
+        t_host = timed(lambda: ctx.canny(img, 2.0, 50, 150), 1)
+        out["C4_single_16k_sigma2.0"] = {
+            "device_resident_ms": round(t_dev * 1e3, 3), "device_resident_Mpix_s": round(H * W / t_dev / 1e6, 1),
+            "host_to_host_ms": round(t_host * 1e3, 2), "host_to_host_Mpix_s": round(H * W / t_host / 1e6, 1),
+            "hysteresis_sweeps": ctx.last_hysteresis_iterations}
+        ctx.free(d_in)
+        ctx.free(d_out)
+    ctx.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):
+                self._L.canny_hip_host_free(self._h, C.c_void_p(p))
+            self._pinned = []
             self._L.canny_hip_ctx_destroy(self._h)
             self._h = None
 
@@ -277,11 +280,26 @@ class Context:
                                             _hp(out)), "canny")
         return out
 
-    def canny_batch(self, imgs, sigma: float, min_val: int, max_val: int) -> np.ndarray:
+    def pinned_array(self, shape, dtype) -> np.ndarray:
+        """numpy array over page-locked host memory (canny_hip_host_alloc); freed when the context closes.
+        canny_batch DMA's pinned inputs/outputs in place instead of staging them."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self._L.canny_hip_host_alloc(self._h, C.byref(p), nbytes), "host_alloc")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def canny_batch(self, imgs, sigma: float, min_val: int, max_val: int, out: Optional[np.ndarray] = None) -> np.ndarray:
         a = np.ascontiguousarray(imgs, dtype=np.uint8)
         if a.ndim != 3:
             raise ValueError("expected uint8 [n_frames, H, W]")
-        out = np.empty(a.shape, np.int16)
+        if out is None:
+            out = np.empty(a.shape, np.int16)
+        elif out.shape != a.shape or out.dtype != np.int16 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous int16 array of the input's shape")
         self._check(self._L.canny_hip_canny_batch(self._h, _hp(a), a.shape[0], sigma, min_val, max_val, a.shape[1],
                                                   a.shape[2], _hp(out)), "canny_batch")
         return out

@@ -630,6 +630,16 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
     std::vector<int> status(n_workers, CANNY_HIP_OK);
     std::vector<std::string> errors(n_workers);
     const int device = ctx->device;
+    // Buffers from canny_hip_host_alloc (or any hipHostMalloc / hipHostRegister'd memory) need no staging.
+    auto is_pinned = [](const void *p) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return attr.type == hipMemoryTypeHost;
+    };
+    const bool in_pinned = is_pinned(imgs), out_pinned = is_pinned(edges);
     auto worker = [&](int wid) {
         canny_hip_ctx *sub = nullptr;
         int st = canny_hip_ctx_create(&sub, device);
@@ -641,8 +651,10 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
         short *pin_out = nullptr;
         void *d_in = nullptr, *d_out = nullptr;
         const size_t in_bytes = frame_px * chunk, out_bytes = frame_px * chunk * sizeof(short);
-        hipError_t e = hipHostMalloc((void **)&pin_in, in_bytes);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&pin_out, out_bytes);
+        hipError_t e = hipSuccess;
+        // pageable caller buffers are staged through pinned memory; pinned ones are DMA'd in place
+        if (!in_pinned) e = hipHostMalloc((void **)&pin_in, in_bytes);
+        if (e == hipSuccess && !out_pinned) e = hipHostMalloc((void **)&pin_out, out_bytes);
         if (e == hipSuccess) e = hipMalloc(&d_in, in_bytes);
         if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
         if (e != hipSuccess) {
@@ -650,8 +662,12 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
         } else {
             for (int c = wid; c < n_chunks && status[wid] == CANNY_HIP_OK; c += n_workers) {
                 int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
-                std::memcpy(pin_in, imgs + (size_t)f0 * frame_px, frame_px * nf);
-                e = hipMemcpyAsync(d_in, pin_in, frame_px * nf, hipMemcpyHostToDevice, sub->stream);
+                const unsigned char *src = imgs + (size_t)f0 * frame_px;
+                if (!in_pinned) {
+                    std::memcpy(pin_in, src, frame_px * nf);
+                    src = pin_in;
+                }
+                e = hipMemcpyAsync(d_in, src, frame_px * nf, hipMemcpyHostToDevice, sub->stream);
                 if (e != hipSuccess) {
                     status[wid] = fail(sub, e, "batch H2D");
                     break;
@@ -662,13 +678,15 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
                     status[wid] = st;
                     break;
                 }
-                e = hipMemcpyAsync(pin_out, d_out, frame_px * nf * sizeof(short), hipMemcpyDeviceToHost, sub->stream);
+                short *dst = edges + (size_t)f0 * frame_px;
+                e = hipMemcpyAsync(out_pinned ? dst : pin_out, d_out, frame_px * nf * sizeof(short),
+                                   hipMemcpyDeviceToHost, sub->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(sub->stream);
                 if (e != hipSuccess) {
                     status[wid] = fail(sub, e, "batch D2H");
                     break;
                 }
-                std::memcpy(edges + (size_t)f0 * frame_px, pin_out, frame_px * nf * sizeof(short));
+                if (!out_pinned) std::memcpy(dst, pin_out, frame_px * nf * sizeof(short));
             }
         }
         if (status[wid] != CANNY_HIP_OK) errors[wid] = sub->last_error;

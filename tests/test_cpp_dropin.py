@@ -1,0 +1,84 @@
+"""The C++ drop-in layer (include/utils.h, include/cuda.h, libcanny_utils.so) and the CLI.
+
+* building tests/cpp/test_utils_dropin.cpp against the drop-in headers proves the reference's own test
+  source would compile against them (same names, same reference-to-pointer signatures) -- CPU, no GPU needed;
+* running it on the GPU replays the reference's known-answer vectors through the C++ names with the
+  reference's new[]/delete[] ownership;
+* `Main` is run end to end on a PGM frame and its output compared with the oracle.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from canny_edge_amd.synth import synth_frame
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "canny_edge_amd")
+EXE = os.path.join(ROOT, "tests", "cpp", "test_utils_dropin")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _build():
+    src = os.path.join(ROOT, "tests", "cpp", "test_utils_dropin.cpp")
+    deps = [src, os.path.join(ROOT, "include", "utils.h"), os.path.join(ROOT, "include", "cuda.h"),
+            os.path.join(PKG, "libcanny_utils.so")]
+    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
+        return
+    subprocess.check_call([HIPCC, "-std=c++14", "-O1", "-x", "c++", src, "-x", "none", "-I" + os.path.join(ROOT, "include"),
+                           "-L" + PKG, "-lcanny_utils", "-lcanny_hip", "-Wl,-rpath," + PKG, "-o", EXE])
+
+
+def test_reference_test_source_shape_compiles_against_dropin_headers():
+    _build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_reference_vectors_through_cpp_dropin():
+    _build()
+    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", "test_gray_256x256.u8")], capture_output=True,
+                       text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 failures" in r.stdout
+
+
+def _write_pgm(path, img):
+    with open(path, "wb") as f:
+        f.write(b"P5\n# written by the test-suite\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+        f.write(img.tobytes())
+
+
+def _read_pgm(path):
+    data = open(path, "rb").read()
+    parts = data.split(b"\n", 3)
+    assert parts[0] == b"P5"
+    w, h = map(int, parts[1].split())
+    assert parts[2] == b"255"
+    return np.frombuffer(parts[3], np.uint8, count=w * h).reshape(h, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["-c"], ["-s"], ["-c", "-s"]])
+def test_cli_end_to_end(tmp_path, flags):
+    """./Main sigma minVal maxVal [-c] [-s] on a PGM frame: the written edge map equals the oracle's."""
+    img = synth_frame(480, 640, 5)
+    _write_pgm(tmp_path / "frame.pgm", img)
+    exe = os.path.join(PKG, "Main")
+    # positionals interleaved with flags, as the reference's parser allows (src/main.cpp:29-46)
+    cmd = [exe, "1.4"] + flags + ["50", "-i", str(tmp_path / "frame.pgm"), "150", "-o", str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Execution time:" in r.stdout
+    got = _read_pgm(tmp_path / "canny_edges.pgm")
+    want = oracle.canny(img, 1.4, 50, 150, stages=True)
+    assert np.array_equal(got, want["edges"].astype(np.uint8))       # {0,255} survives min-max normalisation
+    if "-s" in flags:
+        sm = _read_pgm(tmp_path / "canny_step1_gaussian.pgm")
+        ref = want["smoothed"].astype(np.float64)
+        norm = np.rint((ref - ref.min()) * (255.0 / (ref.max() - ref.min()))).astype(np.uint8)
+        assert np.array_equal(sm, norm)
+        assert os.path.exists(tmp_path / "canny_step2_gradient.pgm")
+        assert os.path.exists(tmp_path / "canny_step3_nonmaximal.pgm")

@@ -44,13 +44,13 @@ def main():
         ms, n = ctx.profile_get(stage)
         return ms / max(n, 1)
 
-    configs = [("pf2_segauto", 2, 0), ("pf5_segauto", 5, 0), ("pf2_seg32", 2, 32), ("pf2_seg48", 2, 48),
-               ("pf2_seg64", 2, 64), ("pf2_seg90", 2, 90), ("pf2_seg120", 2, 120), ("pf2_seg180", 2, 180),
-               ("pf2_seg360", 2, 360), ("pf5_seg360", 5, 360), ("pf2_seg270", 2, 270), ("pf2_seg216", 2, 216)]
+    # (name, unused dynamic LDS in KB per workgroup [64 KB -> 2 waves/SIMD instead of 3], rows per segment)
+    # (name, unused, rows per segment; 0 = the launcher's own choice)
+    configs = [("segauto", 0, 0), ("seg32", 0, 32), ("seg64", 0, 64), ("seg96", 0, 96), ("seg180", 0, 180),
+               ("seg360", 0, 360)]
     res = {name: [] for name, _, _ in configs}
     for _ in range(args.rounds):
-        for name, pf, seg in configs:
-            ctx.set_option("tune_sobel_prefetch", pf)
+        for name, _unused, seg in configs:
             ctx.set_option("tune_sobel_seg", seg)
             res[name].append(time_stage(lambda: ctx.dev_sobel_nms(d_sm, H, W, F, d_out), capi.STAGE_SOBEL_NMS))
     alg = 4.0 * F * H * W
@@ -59,7 +59,6 @@ def main():
         v = res[name]
         med, mn = statistics.median(v), min(v)
         print(f"  {name:14s} median {med:.4f} ms  min {mn:.4f} ms   {alg / med / 1e6:.0f} GB/s  ({alg / med / 8e9 * 100:.1f}% of 8 TB/s)")
-    ctx.set_option("tune_sobel_prefetch", 0)
     ctx.set_option("tune_sobel_seg", 0)
 
     g = [time_stage(lambda: ctx.dev_gaussian(d_img, args.sigma, H, W, F, d_sm), capi.STAGE_GAUSSIAN)

@@ -640,18 +640,24 @@ __device__ __forceinline__ uint32_t pk_sub_sat_i16(uint32_t a, uint32_t b)
 // a wave covers a 64-pixel x 8-row patch, reads eight 128-byte row segments and writes 64 CONTIGUOUS
 // plane bytes (byte stores at the old row-major mapping hit eight 512-byte-strided words per wave and
 // cost 4.6x write amplification in WRITE_SIZE).
-// Launched on a 3-D grid (2*tiles_x, tiles_y, n_frames) of 256-thread workgroups: a workgroup is half a
-// tile (32 rows), so no thread ever divides (a flat index needed two 64-bit divisions per thread, which was
-// most of these kernels' VALU time).
-__device__ __forceinline__ bool patch_coords(const HystGeom &g, size_t &i, int &f, int &y, int &x0)
+// Launched on a 3-D grid (ceil(tiles_x/2), tiles_y, n_frames) of 256-thread workgroups: a workgroup owns two
+// horizontally adjacent tiles and every thread four 8-pixel groups (k = 0..3), so no thread ever divides
+// (a flat index needed two 64-bit divisions per thread) and each thread keeps four 16-byte accesses in flight
+// (one group per thread meant a million single-load waves per launch: wave-launch bound).
+constexpr int kPatchItems = 4;
+__device__ __forceinline__ bool patch_coords(const HystGeom &g, int k, size_t &i, int &f, int &y, int &x0)
 {
-    const int tx = (int)(blockIdx.x >> 1), ty = (int)blockIdx.y;
-    const int within = (int)((blockIdx.x & 1u) * 256u + threadIdx.x);
+    const int tx = (int)blockIdx.x * 2 + (k >> 1), ty = (int)blockIdx.y;
+    const int within = (k & 1) * 256 + (int)threadIdx.x;
     f = (int)blockIdx.z;
     i = ((((size_t)f * g.tiles_y + ty) * g.tiles_x + tx) << 9) + within;
     y = ty * kTile + (within >> 3);
     x0 = tx * kTile + (within & 7) * 8;
-    return y < g.height && x0 < g.width; // width % 8 == 0: a group is entirely inside or outside
+    return tx < g.tiles_x && y < g.height && x0 < g.width; // width % 8 == 0: a group is all inside or all outside
+}
+__device__ __forceinline__ bool patch_tile_exists(const HystGeom &g, int k)
+{
+    return (int)blockIdx.x * 2 + (k >> 1) < g.tiles_x;
 }
 
 __global__ __launch_bounds__(256) void hyst_classify8_kernel(const int16_t *__restrict__ cand,
@@ -660,13 +666,23 @@ __global__ __launch_bounds__(256) void hyst_classify8_kernel(const int16_t *__re
 {
     const bool fast = lo >= -32768 && lo <= 32767 && hi >= -32768 && hi <= 32767; // wave-uniform
     const uint32_t lo2 = ((uint32_t)lo & 0xffffu) * 0x10001u, hi2 = ((uint32_t)hi & 0xffffu) * 0x10001u;
-    {
+    uint4 px4[kPatchItems];
+    size_t idx[kPatchItems];
+    bool inside[kPatchItems];
+#pragma unroll
+    for (int k = 0; k < kPatchItems; k++) { // all loads first
         int f, y, x0;
-        size_t i;
+        inside[k] = patch_coords(g, k, idx[k], f, y, x0);
+        px4[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (inside[k]) __builtin_memcpy(&px4[k], cand + ((size_t)f * g.height + y) * g.width + x0, 16);
+    }
+#pragma unroll
+    for (int k = 0; k < kPatchItems; k++) {
+        if (!patch_tile_exists(g, k)) continue; // odd tiles_x: the second tile of the last workgroup
+        const size_t i = idx[k];
         unsigned cbits = 0, sbits = 0;
-        if (patch_coords(g, i, f, y, x0)) {
-            uint4 v;
-            __builtin_memcpy(&v, cand + ((size_t)f * g.height + y) * g.width + x0, 16);
+        if (inside[k]) {
+            const uint4 v = px4[k];
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             if (fast) {
                 // Packed path (thresholds fit a short): 4.3 VALU ops per pixel instead of 18.7.
@@ -713,10 +729,11 @@ __global__ __launch_bounds__(256) void hyst_finalize8_kernel(int16_t *__restrict
                                                              int edge_value)
 {
     const uint32_t ev = (uint32_t)(uint16_t)edge_value;
-    {
+#pragma unroll
+    for (int k = 0; k < kPatchItems; k++) {
         int f, y, x0;
         size_t i;
-        if (!patch_coords(g, i, f, y, x0)) return;
+        if (!patch_coords(g, k, i, f, y, x0)) continue;
         const unsigned b = strong[i];
         // bit 2k -> bit 0 and bit 2k+1 -> bit 16 of register k, then one 24-bit multiply by the edge value
         const uint32_t t = b | (b << 15);
@@ -734,7 +751,7 @@ hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t 
 {
     size_t n_words = (size_t)g.n_frames * g.tiles_y * kTile * g.tiles_x;
     if (g.width % 8 == 0)
-        hipLaunchKernelGGL(hyst_classify8_kernel, dim3(2 * g.tiles_x, g.tiles_y, g.n_frames), dim3(256), 0, stream,
+        hipLaunchKernelGGL(hyst_classify8_kernel, dim3((g.tiles_x + 1) / 2, g.tiles_y, g.n_frames), dim3(256), 0, stream,
                            cand, (uint8_t *)strong, (uint8_t *)conn, g, min_val, max_val, domain_flag);
     else
         hipLaunchKernelGGL(hyst_classify_kernel, dim3(grid_for(n_words * 64, 256)), dim3(256), 0, stream, cand,
@@ -755,7 +772,7 @@ hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const Hys
 {
     size_t total = (size_t)g.n_frames * g.height * g.width;
     if (g.width % 8 == 0)
-        hipLaunchKernelGGL(hyst_finalize8_kernel, dim3(2 * g.tiles_x, g.tiles_y, g.n_frames), dim3(256), 0, stream, cand,
+        hipLaunchKernelGGL(hyst_finalize8_kernel, dim3((g.tiles_x + 1) / 2, g.tiles_y, g.n_frames), dim3(256), 0, stream, cand,
                            (const uint8_t *)strong, g, edge_value);
     else
         hipLaunchKernelGGL(hyst_finalize_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, cand, strong, g,

@@ -41,7 +41,8 @@ EXPORTS = (
     "canny_hip_canny_multi_gpu", "canny_hip_shard_range", "canny_hip_dev_gaussian", "canny_hip_dev_xy_gradient",
     "canny_hip_dev_sobel", "canny_hip_dev_nms", "canny_hip_dev_sobel_nms", "canny_hip_dev_hysteresis",
     "canny_hip_dev_canny", "canny_hip_profile_enable", "canny_hip_profile_reset", "canny_hip_profile_get",
-    "canny_hip_selftest_mag_angle", "canny_hip_selftest_div",
+    "canny_hip_selftest_mag_angle", "canny_hip_selftest_div", "canny_hip_selftest_div_fma",
+    "canny_hip_selftest_div_fma_table",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -108,6 +109,8 @@ def load() -> C.CDLL:
         "canny_hip_profile_get": ([p, i, C.POINTER(C.c_double), C.POINTER(C.c_long)], i),
         "canny_hip_selftest_mag_angle": ([p, i, p, p], i),
         "canny_hip_selftest_div": ([p, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
+        "canny_hip_selftest_div_fma": ([p, f, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
+        "canny_hip_selftest_div_fma_table": ([i, C.POINTER(C.c_float), C.POINTER(C.c_float)], i),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -125,6 +128,17 @@ def device_count() -> int:
     n = C.c_int(0)
     load().canny_hip_device_count(C.byref(n))
     return n.value
+
+
+def fma_div_table():
+    """The (divisor, c) pairs for which the Gaussian kernels replace a/divisor by fma(a, c, a)."""
+    out, k = [], 0
+    while True:
+        s, c = C.c_float(0), C.c_float(0)
+        if load().canny_hip_selftest_div_fma_table(k, C.byref(s), C.byref(c)):
+            return out
+        out.append((s.value, c.value))
+        k += 1
 
 
 def shard_range(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
@@ -316,6 +330,13 @@ class Context:
         a/divisor over all floats a in [0,256]."""
         bad, worst = C.c_ulonglong(0), C.c_float(0.0)
         self._check(self._L.canny_hip_selftest_div(self._h, divisor, C.byref(bad), C.byref(worst)), "selftest_div")
+        return bad.value, worst.value
+
+    def selftest_div_fma(self, divisor: float, c: float) -> Tuple[int, float]:
+        """Same for the one-instruction form fma(a, c, a)."""
+        bad, worst = C.c_ulonglong(0), C.c_float(0.0)
+        self._check(self._L.canny_hip_selftest_div_fma(self._h, divisor, c, C.byref(bad), C.byref(worst)),
+                    "selftest_div_fma")
         return bad.value, worst.value
 
     # ---- device-pointer stage API (ints are device addresses; n_frames contiguous planes) -------

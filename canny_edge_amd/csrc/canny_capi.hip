@@ -397,6 +397,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "tune_sobel_prefetch") && (value == 0 || value == 2 || value == 5))
         ctx->tune_sobel_prefetch = value;
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
+    else if (!std::strcmp(name, "gaussian_fma_div") && value <= 1) gaussian_set_fma_div(value != 0); // process-wide
     else return CANNY_HIP_ERR_INVALID;
     return CANNY_HIP_OK;
 }
@@ -887,8 +888,8 @@ int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes,
     return d2h_sync(ctx, bins, ctx->io[1].p, total);
 }
 
-int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches,
-                           float *largest_mismatching_dividend)
+static int selftest_div_common(canny_hip_ctx *ctx, float divisor, int use_fma, float c,
+                               unsigned long long *mismatches, float *largest_mismatching_dividend)
 {
     int rc = bind(ctx);
     if (rc) return rc;
@@ -897,13 +898,35 @@ int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long
     HIP_TRY(ctx, ctx->io[0].ensure(2 * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->io[0].p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     const unsigned last = 0x43800000u; // bit pattern of 256.0f; non-negative floats are ordered like their bits
-    HIP_TRY(ctx, launch_selftest_div(divisor, 0u, last, (unsigned long long *)ctx->io[0].p, ctx->stream));
+    HIP_TRY(ctx, launch_selftest_div(divisor, use_fma, c, 0u, last, (unsigned long long *)ctx->io[0].p, ctx->stream));
     unsigned long long res[2] = {0, 0};
     if ((rc = d2h_sync(ctx, res, ctx->io[0].p, sizeof(res)))) return rc;
     *mismatches = res[0];
     unsigned bits = (unsigned)res[1];
     std::memcpy(largest_mismatching_dividend, &bits, sizeof(float));
     return CANNY_HIP_OK;
+}
+
+int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches,
+                           float *largest_mismatching_dividend)
+{
+    return selftest_div_common(ctx, divisor, 0, 0.0f, mismatches, largest_mismatching_dividend);
+}
+
+int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c)
+{
+    const unsigned(*table)[2] = nullptr;
+    const int n = gaussian_fma_div_table(&table);
+    if (index < 0 || index >= n || !divisor || !c) return CANNY_HIP_ERR_INVALID;
+    std::memcpy(divisor, &table[index][0], sizeof(float));
+    std::memcpy(c, &table[index][1], sizeof(float));
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_selftest_div_fma(canny_hip_ctx *ctx, float divisor, float c, unsigned long long *mismatches,
+                               float *largest_mismatching_dividend)
+{
+    return selftest_div_common(ctx, divisor, 1, c, mismatches, largest_mismatching_dividend);
 }
 
 } // extern "C"

@@ -26,6 +26,7 @@
 // in SGPRs.
 #include "canny_kernels.h"
 
+#include <cstring>
 #include <type_traits>
 
 namespace canny {
@@ -67,9 +68,14 @@ struct GaussJob {
     int H, W, ybeg, yend, x0, lane;
 };
 
-template <int C, bool COL_EDGE, bool ROW_EDGE>
-__device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const GaussTaps &t, float *rowbuf, float *colring)
+// FMA_DIV (interior waves only, where every divisor is the full-window weight S): a / S as the single
+// instruction fma(a, fma_c, a).  The host enables it only for the (S, c) pairs of kFmaDivTable, each of
+// which canny_hip_selftest_div_fma has shown to equal the IEEE quotient for every float a in [0, 256].
+template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV = false>
+__device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const GaussTaps &t, float *rowbuf, float *colring,
+                                                  float fma_c = 0.0f)
 {
+    static_assert(!FMA_DIV || (!COL_EDGE && !ROW_EDGE), "FMA_DIV needs a single wave-uniform divisor");
     using K = MarchCfg<C>;
     constexpr int HL = K::HL, RING = K::RING, WIN = K::WIN;
     const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend, lane = jb.lane;
@@ -150,7 +156,7 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
                 float acc = __fmul_rn(wv[4 * HL + j - C], t.tap[0]);
 #pragma unroll
                 for (int k = 1; k < RING; k++) acc = __fadd_rn(acc, __fmul_rn(wv[4 * HL + j - C + k], t.tap[k]));
-                res[j] = div_by(acc, cnt_h[j], inv_h[j]);
+                res[j] = FMA_DIV ? __fmaf_rn(acc, fma_c, acc) : div_by(acc, cnt_h[j], inv_h[j]);
             }
             tmp = make_float4(res[0], res[1], res[2], res[3]);
         }
@@ -189,8 +195,9 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
             }
             if (owner) {
                 // float -> short truncates toward zero (src/utils.cpp:62)
-                const int o0 = (int)div_by(acc[0], cnt_v, inv_v), o1 = (int)div_by(acc[1], cnt_v, inv_v);
-                const int o2 = (int)div_by(acc[2], cnt_v, inv_v), o3 = (int)div_by(acc[3], cnt_v, inv_v);
+                auto quot = [&](float a) { return FMA_DIV ? __fmaf_rn(a, fma_c, a) : div_by(a, cnt_v, inv_v); };
+                const int o0 = (int)quot(acc[0]), o1 = (int)quot(acc[1]);
+                const int o2 = (int)quot(acc[2]), o3 = (int)quot(acc[3]);
                 int16_t *dst = jb.fout + (size_t)y * W + x0;
                 if (!COL_EDGE || full4) {
                     uint2 pk;
@@ -227,7 +234,7 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
 template <int C>
 __global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
     const uint8_t *__restrict__ img, int16_t *__restrict__ out, int H, int W, int n_strips, int n_segs, int seg_rows,
-    int total_waves, GaussTaps t)
+    int total_waves, GaussTaps t, int use_fma_div, float fma_c)
 {
     using K = MarchCfg<C>;
     __shared__ __attribute__((aligned(16))) float lds[K::WPB * K::WAVE_FLOATS];
@@ -269,14 +276,41 @@ __global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
     } else {
         if (row_edge)
             gauss_march_strip<C, false, true>(jb, t, rowbuf, colring);
+        else if (use_fma_div)
+            gauss_march_strip<C, false, false, true>(jb, t, rowbuf, colring, fma_c);
         else
             gauss_march_strip<C, false, false>(jb, t, rowbuf, colring);
     }
 }
 
+// Full-window weights S (bit patterns) for which a / S == fma(a, c, a) for EVERY float a in [0, 256];
+// found and re-verified exhaustively on the device (tools/probe_div_fma.py, tests/test_gpu_numerics.py).
+// S = 1 - 4..+2 ulps covers what the normalised taps sum to in practice (sigma 0.8/1.0/2.5 give exactly 1,
+// 0.5/1.2/1.6 give 1 - 2^-24, 1.4/2.0 give 1 + 2^-23); any other S keeps the 5-op division.
+static const unsigned kFmaDivTable[][2] = {
+    {0x3f800000u, 0x00000000u}, // S = 1                c = 0
+    {0x3f800001u, 0xb3fffffeu}, // S = 1 + 2^-23        c = -(2^-23 - 2^-46)
+    {0x3f800002u, 0xb47ffffcu}, // S = 1 + 2^-22        c = -(2^-22 - 2^-44)
+    {0x3f7fffffu, 0x33800001u}, // S = 1 - 2^-24        c = 2^-24 + 2^-47
+    {0x3f7ffffeu, 0x34000001u}, // S = 1 - 2^-23        c = 2^-23 + 2^-46
+    {0x3f7ffffdu, 0x34400003u}, // S = 1 - 3*2^-24
+    {0x3f7ffffcu, 0x34800002u}, // S = 1 - 2^-22        c = 2^-22 + 2^-44
+};
+
+int gaussian_fma_div_table(const unsigned (**table)[2])
+{
+    *table = kFmaDivTable;
+    return (int)(sizeof(kFmaDivTable) / sizeof(kFmaDivTable[0]));
+}
+
+static bool fma_div_enabled = true; // A/B switch (canny_hip_ctx_set_option "gaussian_fma_div")
+void gaussian_set_fma_div(bool on) { fma_div_enabled = on; }
+
 // ---- exhaustive check of div_by against the IEEE divide (test hook) -----------------------------------
-__global__ __launch_bounds__(256) void selftest_div_kernel(float b, unsigned first_bits, unsigned last_bits,
-                                                           unsigned long long *mismatches)
+// fma_c == 0: the 5-op div_by;  fma_c != 0 (passed as a bit pattern so that c = 0.0f is expressible through
+// use_fma): the one-instruction candidate a/b ~ fma(a, c, a) used for the full-window weight b = 1 +- ulp.
+__global__ __launch_bounds__(256) void selftest_div_kernel(float b, int use_fma, float c, unsigned first_bits,
+                                                           unsigned last_bits, unsigned long long *mismatches)
 {
     const float y = __fdiv_rn(1.0f, b);
     unsigned long long bad = 0, worst = 0;
@@ -285,7 +319,7 @@ __global__ __launch_bounds__(256) void selftest_div_kernel(float b, unsigned fir
          u += stride) {
         const float a = __uint_as_float((unsigned)u);
         const float want = __fdiv_rn(a, b);
-        const float got = div_by(a, b, y);
+        const float got = use_fma ? __fmaf_rn(a, c, a) : div_by(a, b, y);
         if (__float_as_uint(want) != __float_as_uint(got)) {
             bad++;
             worst = u; // u ascends within a thread
@@ -297,10 +331,10 @@ __global__ __launch_bounds__(256) void selftest_div_kernel(float b, unsigned fir
     }
 }
 
-hipError_t launch_selftest_div(float b, unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,
-                               hipStream_t stream)
+hipError_t launch_selftest_div(float b, int use_fma, float c, unsigned first_bits, unsigned last_bits,
+                               unsigned long long *d_mismatches, hipStream_t stream)
 {
-    hipLaunchKernelGGL(selftest_div_kernel, dim3(256 * 16), dim3(256), 0, stream, b, first_bits, last_bits,
+    hipLaunchKernelGGL(selftest_div_kernel, dim3(256 * 16), dim3(256), 0, stream, b, use_fma, c, first_bits, last_bits,
                        d_mismatches);
     return hipGetLastError();
 }
@@ -318,8 +352,21 @@ static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, i
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;
     unsigned blocks = (unsigned)((waves + K::WPB - 1) / K::WPB);
+    // full-window weight, summed exactly like the kernel (and the reference) does: ascending float adds
+    volatile float s = taps.tap[0]; // volatile: keep the host compiler from re-associating / widening
+    for (int k = 1; k < K::RING; k++) s = s + taps.tap[k];
+    const float full = s;
+    unsigned full_bits;
+    std::memcpy(&full_bits, &full, sizeof(full_bits));
+    int use_fma = 0;
+    float fma_c = 0.0f;
+    for (const auto &e : kFmaDivTable)
+        if (e[0] == full_bits && fma_div_enabled) {
+            use_fma = 1;
+            std::memcpy(&fma_c, &e[1], sizeof(fma_c));
+        }
     hipLaunchKernelGGL(gauss_march_kernel<C>, dim3(blocks), dim3(K::WPB * 64), 0, stream, img, out, height, width,
-                       n_strips, n_segs, seg, (int)waves, taps);
+                       n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
     return hipGetLastError();
 }
 

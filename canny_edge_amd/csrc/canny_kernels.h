@@ -48,6 +48,12 @@ bool gaussian_march_supported(int center, int height, int width);
 hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, int width, int n_frames,
                                  const GaussTaps &taps, hipStream_t stream);
 
+// (S, c) bit-pattern pairs for which the interior waves divide by the full-window weight S with one
+// fma(a, c, a); returns the number of entries.  gaussian_set_fma_div(false) disables the shortcut
+// process-wide (A/B measurements only).
+int gaussian_fma_div_table(const unsigned (**table)[2]);
+void gaussian_set_fma_div(bool on);
+
 // ---- Sobel / NMS (src/utils.cpp:106-308) ----------------------------------------------------
 hipError_t launch_xy_gradient(const int16_t *img, int16_t *gx, int16_t *gy, int height, int width, int n_frames,
                               hipStream_t stream);
@@ -84,7 +90,8 @@ hipError_t launch_fep_finalize(int16_t *cand, uint8_t *visited, const uint64_t *
 hipError_t launch_selftest_mag_angle(int lim, int16_t *mags, uint8_t *bins, hipStream_t stream);
 // Counts floats a (bit patterns first_bits..last_bits) for which the Gaussian's reciprocal-based
 // division a/b differs from the IEEE divide; *d_mismatches must be zero beforehand.
-hipError_t launch_selftest_div(float b, unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,
-                               hipStream_t stream);
+// use_fma != 0 checks the one-instruction form fma(a, c, a) instead of the 5-op reciprocal division.
+hipError_t launch_selftest_div(float b, int use_fma, float c, unsigned first_bits, unsigned last_bits,
+                               unsigned long long *d_mismatches, hipStream_t stream);
 
 } // namespace canny

@@ -90,7 +90,9 @@ int canny_hip_ctx_set_stream(canny_hip_ctx *ctx, void *hip_stream);
 int canny_hip_ctx_device(const canny_hip_ctx *ctx);
 /* Kernel-path selection, for A/B measurements and tests; every path gives identical results.
  *   "gaussian_path":  0 auto (default), 1 generic two-pass, 2 wave-marching (window <= 17)
- *   "sobel_nms_path": 0 auto (default), 1 LDS-tiled, 2 wave-marching */
+ *   "sobel_nms_path": 0 auto (default), 1 LDS-tiled, 2 wave-marching
+ *   "gaussian_fma_div": 1 (default) / 0 -- single-fma division by the full-window weight (process-wide)
+ *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic */
 int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value);
 int canny_hip_synchronize(canny_hip_ctx *ctx);
 /* Text of the last HIP runtime error seen by this context ("" if none). */
@@ -173,6 +175,12 @@ int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes,
  * *largest_mismatching_dividend the largest a that differed (0 if none). */
 int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long *mismatches,
                            float *largest_mismatching_dividend);
+/* Same comparison for the one-instruction form a/divisor ~ fma(a, c, a) that the interior Gaussian waves
+ * use when the full-window weight is within an ulp of 1 (c = 0 when it is exactly 1). */
+int canny_hip_selftest_div_fma(canny_hip_ctx *ctx, float divisor, float c, unsigned long long *mismatches,
+                               float *largest_mismatching_dividend);
+/* Entry `index` of the built-in (divisor, c) table the kernels use; CANNY_HIP_ERR_INVALID past the end. */
+int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c);
 
 #ifdef __cplusplus
 }

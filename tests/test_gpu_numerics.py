@@ -44,6 +44,35 @@ def test_reciprocal_division_matches_ieee_for_every_dividend(hip):
     assert len(res) > 60
 
 
+def test_single_fma_division_table_is_exact_for_every_dividend(hip):
+    """Interior Gaussian waves divide by the full-window weight S with ONE instruction, fma(a, c, a), when
+    (S, c) is in the kernels' built-in table.  Every entry must equal the IEEE quotient for every float a in
+    [0, 256] -- all 1.13e9 of them, no exceptions (not even the tiny dividends the 5-op form misses)."""
+    table = hip.fma_div_table()
+    assert len(table) >= 7 and (1.0, 0.0) in table
+    with hip.Context(0) as c:
+        for s, cc in table:
+            bad, worst = c.selftest_div_fma(s, cc)
+            assert bad == 0, f"fma(a, {cc!r}, a) != a / {s!r} for {bad} dividends (largest {worst!r})"
+        # and the check itself can fail: a wrong constant is caught
+        bad, _ = c.selftest_div_fma(1.0000001192092896, -1.1920928955078125e-07)
+        assert bad > 0
+
+
+@pytest.mark.parametrize("fma_div", [0, 1])
+def test_gaussian_with_and_without_fma_division(hip, fma_div):
+    """Same bits from both division forms, for sigmas whose full-window weight is 1, 1-2^-24 and 1+2^-23."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(300, 1000), dtype=np.uint8)
+    with hip.Context(0) as c:
+        c.set_option("gaussian_fma_div", fma_div)
+        try:
+            for sigma in (0.5, 1.0, 1.2, 1.4, 2.0, 2.5):
+                assert np.array_equal(c.gaussian(img, sigma), oracle.gaussian(img, sigma)), sigma
+        finally:
+            c.set_option("gaussian_fma_div", 1)
+
+
 @pytest.mark.parametrize("sigma", [0.05, 0.08, 0.1, 0.12, 0.13, 0.14, 0.15, 0.2])
 def test_tiny_sigma_gaussian_is_still_bit_exact(hip, sigma):
     """Taps as small as exp(-1/(2 sigma^2)): denormal and underflowing weights; below the 2^-48 tap gate

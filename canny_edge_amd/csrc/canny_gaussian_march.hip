@@ -33,16 +33,24 @@ namespace canny {
 
 namespace {
 
+template <int V>
+using IC = std::integral_constant<int, V>;
+
 template <int C>
 struct MarchCfg {
     static constexpr int HL = (C + 3) / 4;           // halo lanes per side (4 px each)
-    static constexpr int RING = 2 * C + 1;           // rows in the column ring
+    static constexpr int RING = 2 * C + 1;           // rows the column pass needs (= window)
+    static constexpr int REGROWS = 3;                // the newest rows stay in registers (loop is unrolled by 3)
+    static constexpr int LROWS = RING - REGROWS;     // older rows live in the LDS ring
     static constexpr int WIN = 4 + 8 * HL;           // floats a lane reads back per row
     static constexpr int SW = (64 - 2 * HL) * 4;     // output columns per strip
     static constexpr int ROWBUF = (64 + 2 * HL) * 4; // floats
-    static constexpr int WAVE_FLOATS = ROWBUF + RING * 256;
+    static constexpr int WAVE_FLOATS = ROWBUF + (LROWS > 0 ? LROWS : 1) * 256;
     static constexpr int WPB = (C <= 6) ? 4 : 2;     // waves per workgroup (LDS budget)
 };
+// LDS per wave = 1.1 KB row buffer + LROWS KB: 9.1 KB at window 11 -> 16 waves per CU (4 per SIMD).  With
+// the whole ring in LDS (12.4 KB) only 3 waves per SIMD fit, and this kernel is bound by per-wave issue
+// latency, not by the VALU pipe (55 % busy at 3 waves), so resident waves are what buys speed.
 
 // Orders this wave's LDS accesses in program order for the COMPILER (the hardware already executes one
 // wave's DS instructions in order).  A wavefront-scope fence emits no instruction and, unlike
@@ -124,11 +132,21 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
         return v;
     };
 
-    int wslot = 0; // ring slot the next row-pass result goes to
-    int oslot = 0; // ring slot holding tap 0 of the next output row
+    constexpr int LROWS = K::LROWS;
+    int wslot = 0; // LDS ring slot the next evicted row goes to (row i of this segment -> slot i mod LROWS)
+    int oslot = 0; // LDS ring slot holding tap 0 of the next output row
+    float4 recent[3]; // row-pass results of rows r, r-1, r-2; slot = (row - rfirst) mod 3
+    recent[0] = recent[1] = recent[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int rfirst0 = ybeg - C;
 
-    auto step = [&](int r, uint32_t cur) {
-        // ---- row pass of input row r -> ring[wslot] ------------------------------------------------
+    auto step = [&](auto ph, int r, uint32_t cur) {
+        constexpr int PH = decltype(ph)::value; // (r - rfirst) mod 3
+        // ---- the row that leaves the register window (r-3) moves to the LDS ring ----------------------
+        if (LROWS > 0 && r - rfirst0 >= 3) {
+            *reinterpret_cast<float4 *>(colring + wslot * 256) = recent[PH];
+            wslot = (wslot + 1 == LROWS) ? 0 : wslot + 1;
+        }
+        // ---- row pass of input row r -> recent[PH] --------------------------------------------------
         float4 tmp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (!ROW_EDGE || (r >= 0 && r < H)) {
             float4 own = make_float4((float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
@@ -160,10 +178,10 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
             }
             tmp = make_float4(res[0], res[1], res[2], res[3]);
         }
-        *reinterpret_cast<float4 *>(colring + wslot * 256) = tmp;
-        wslot = (wslot + 1 == RING) ? 0 : wslot + 1;
+        recent[PH] = tmp;
 
         // ---- column pass of output row y = r - C (its last tap just arrived) -------------------------
+        // taps 0 .. LROWS-1 come from the LDS ring (rows r-2C .. r-3), the last three from registers
         const int y = r - C;
         if (y >= ybeg && y < yend) {
             float cnt_v = cnt_full, inv_v = inv_full;
@@ -178,9 +196,14 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
             float acc[4];
 #pragma unroll
             for (int k = 0; k < RING; k++) {
-                int slot = oslot + k;
-                slot = slot >= RING ? slot - RING : slot;
-                float4 v = *reinterpret_cast<const float4 *>(colring + slot * 256);
+                float4 v;
+                if (k < LROWS) {
+                    int slot = oslot + k;
+                    slot = slot >= LROWS ? slot - LROWS : slot;
+                    v = *reinterpret_cast<const float4 *>(colring + slot * 256);
+                } else {
+                    v = recent[(PH + 1 + (k - LROWS)) % 3]; // k = LROWS, +1, +2  ->  rows r-2, r-1, r
+                }
                 if (k == 0) {
                     acc[0] = __fmul_rn(v.x, t.tap[0]);
                     acc[1] = __fmul_rn(v.y, t.tap[0]);
@@ -211,7 +234,7 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
                 }
             }
         }
-        if (y >= ybeg) oslot = (oslot + 1 == RING) ? 0 : oslot + 1;
+        if (LROWS > 0 && y >= ybeg) oslot = (oslot + 1 == LROWS) ? 0 : oslot + 1;
     };
 
     // Rows ybeg-C .. yend-1+C, count rounded up to a multiple of 3 so that the three prefetch registers
@@ -221,11 +244,11 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
     uint32_t pa = load_row(rfirst), pb = load_row(rfirst + 1), pc;
     for (int r = rfirst; r <= rlast; r += 3) {
         pc = load_row(r + 2);
-        step(r, pa);
+        step(IC<0>{}, r, pa);
         pa = load_row(r + 3);
-        step(r + 1, pb);
+        step(IC<1>{}, r + 1, pb);
         pb = load_row(r + 4);
-        step(r + 2, pc);
+        step(IC<2>{}, r + 2, pc);
     }
 }
 

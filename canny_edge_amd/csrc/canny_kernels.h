@@ -80,6 +80,7 @@ hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigne
                                  int iter, const HystGeom &g, hipStream_t stream);
 hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const HystGeom &g, int edge_value,
                                 hipStream_t stream);
+void hyst_set_finalize_mode(int mode); // A/B: 0 = row-major kernel (default), 1 = 8-row patch kernel
 // findEdgePixels (single frame): seed = {start}, connectable = cand >= min_val && !visited.
 hipError_t launch_fep_classify(const int16_t *cand, const uint8_t *visited, uint64_t *strong, uint64_t *conn,
                                const HystGeom &g, int start, int min_val, hipStream_t stream);

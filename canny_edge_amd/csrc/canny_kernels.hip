@@ -767,11 +767,54 @@ hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigne
                        iter, g);
     return hipGetLastError();
 }
+// Row-major finalize: a wave writes 512 consecutive pixels of ONE row (1 KB contiguous, four rows per
+// thread) and gathers its 64 plane bytes from eight tiles (8 x 8 contiguous bytes, L2 resident).
+__global__ __launch_bounds__(256) void hyst_finalize_rows_kernel(int16_t *__restrict__ cand,
+                                                                 const uint8_t *__restrict__ strong, HystGeom g,
+                                                                 int edge_value, int groups_per_row)
+{
+    // grid: x = 512-pixel chunks of a row (one wave each, 4 per workgroup), y = groups of 4 rows, z = frame
+    const uint32_t ev = (uint32_t)(uint16_t)edge_value;
+    const int chunk = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int gx = chunk * 64 + (int)(threadIdx.x & 63); // 8-pixel group index within the row
+    if (gx >= groups_per_row) return;
+    const int f = (int)blockIdx.z;
+    const int x0 = gx * 8;
+    const size_t tile_col = ((size_t)f * g.tiles_y) * g.tiles_x + (gx >> 3);
+    unsigned b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int y = (int)blockIdx.y * 4 + k;
+        b[k] = 0;
+        if (y < g.height)
+            b[k] = strong[((tile_col + (size_t)(y >> 6) * g.tiles_x) << 9) + (size_t)(y & 63) * 8 + (gx & 7)];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int y = (int)blockIdx.y * 4 + k;
+        if (y >= g.height) break;
+        const uint32_t t = b[k] | (b[k] << 15);
+        uint4 v;
+        v.x = __umul24(t & 0x00010001u, ev);
+        v.y = __umul24((t >> 2) & 0x00010001u, ev);
+        v.z = __umul24((t >> 4) & 0x00010001u, ev);
+        v.w = __umul24((t >> 6) & 0x00010001u, ev);
+        __builtin_memcpy(cand + ((size_t)f * g.height + y) * g.width + x0, &v, 16);
+    }
+}
+
+static int finalize_mode = 0; // A/B switch: 0 = rows kernel, 1 = 8-row patch kernel
+void hyst_set_finalize_mode(int m) { finalize_mode = m; }
+
 hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const HystGeom &g, int edge_value,
                                 hipStream_t stream)
 {
     size_t total = (size_t)g.n_frames * g.height * g.width;
-    if (g.width % 8 == 0)
+    if (g.width % 8 == 0 && finalize_mode == 0) {
+        const int groups = g.width / 8;
+        hipLaunchKernelGGL(hyst_finalize_rows_kernel, dim3((groups + 255) / 256, (g.height + 3) / 4, g.n_frames),
+                           dim3(256), 0, stream, cand, (const uint8_t *)strong, g, edge_value, groups);
+    } else if (g.width % 8 == 0)
         hipLaunchKernelGGL(hyst_finalize8_kernel, dim3((g.tiles_x + 1) / 2, g.tiles_y, g.n_frames), dim3(256), 0, stream, cand,
                            (const uint8_t *)strong, g, edge_value);
     else

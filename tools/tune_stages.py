@@ -72,16 +72,19 @@ def main():
         g = gres[mode]
         print(f"gaussian march [{name}]  median {statistics.median(g):.4f} ms  min {min(g):.4f} ms")
     ctx.dev_sobel_nms(d_sm, H, W, F, d_out)
-    hy = {"hyst_classify": [], "hyst_propagate": [], "hyst_finalize": []}
+    hy = {}
     for _ in range(args.rounds):
-        ctx.dev_sobel_nms(d_sm, H, W, F, d_out)
-        ctx.profile_reset()
-        ctx.dev_hysteresis(d_out, H, W, F, 50, 150)
-        for k, sid in (("hyst_classify", 2), ("hyst_propagate", 3), ("hyst_finalize", 4)):
-            ms, n = ctx.profile_get(sid)
-            hy[k].append(ms)
+        for fmode in (0, 1):
+            ctx.set_option("tune_finalize_mode", fmode)
+            ctx.dev_sobel_nms(d_sm, H, W, F, d_out)
+            ctx.profile_reset()
+            ctx.dev_hysteresis(d_out, H, W, F, 50, 150)
+            for k, sid in (("hyst_classify", 2), ("hyst_propagate", 3), ("hyst_finalize", 4)):
+                ms, n = ctx.profile_get(sid)
+                hy.setdefault(f"{k}[finalize_mode={fmode}]", []).append(ms)
+    ctx.set_option("tune_finalize_mode", 0)
     for k, v in hy.items():
-        print(f"{k:16s} median {statistics.median(v):.4f} ms  min {min(v):.4f} ms")
+        print(f"{k:36s} median {statistics.median(v):.4f} ms  min {min(v):.4f} ms")
     print("hysteresis sweeps:", ctx.last_hysteresis_iterations)
     ctx.close()
 

@@ -67,9 +67,6 @@ __device__ __forceinline__ float div_by(float a, float b, float y)
     return __fmaf_rn(r, y, q);
 }
 
-template <int N>
-using IC = std::integral_constant<int, N>;
-
 struct GaussJob {
     const uint8_t *fimg;
     int16_t *fout;
@@ -252,7 +249,255 @@ __device__ __forceinline__ void gauss_march_strip(const GaussJob &jb, const Gaus
     }
 }
 
+// ---- symmetric-tap variant: shared products, register accumulators, no LDS ---------------------------
+// The reference's taps are symmetric bit for bit (tap[C-a] == tap[C+a]: both come from the same
+// exp(-(a*a)/...) expression, src/utils.cpp:77-95; the launcher re-checks the bit patterns).  The rounded
+// product RN(v * tap) of one value v is therefore needed by TWO outputs, at distance +a and -a, and only
+// C+1 instead of 2C+1 multiplies per value and pass are distinct.  The sums keep the reference's order
+// (ascending tap index, every add rounded); what changes is who computes each product:
+//   row pass     each lane multiplies its own 4 pixels by the C+1 distinct taps; outputs pick the products
+//                of neighbouring pixels out of neighbouring lanes with DPP wave shifts that fold into the
+//                v_add_f32 itself (no LDS row buffer, no extra instruction);
+//   column pass  scatter form: the 2C+1 output rows a row-pass result contributes to are all open at once,
+//                each with its partial sum in registers (slot = phase of the output's first row, the loop
+//                is unrolled by 2C+1 so slots are compile-time).  Row r is tap k of output r+C-k, and the
+//                rows before it have already been added, so the order is still ascending k.
+// VALU work per pixel drops from 2*(2C+1) multiplies to 2*(C+1) (44 -> 24 at window 11; adds unchanged).
+__device__ __forceinline__ float lane_shr1(float v) // lane L <- lane L-1, lane 0 <- 0
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_shl1(float v) // lane L <- lane L+1, lane 63 <- 0
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void for_each_phase(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(IC<I>{}), ...);
+}
+
+template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV = false>
+__device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussTaps &t, float fma_c = 0.0f)
+{
+    static_assert(!FMA_DIV || (!COL_EDGE && !ROW_EDGE), "FMA_DIV needs a single wave-uniform divisor");
+    constexpr int HL = MarchCfg<C>::HL, RING = 2 * C + 1;
+    static_assert(HL <= 2, "products travel at most two lanes");
+    const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend, lane = jb.lane;
+    const bool owner = lane >= HL && lane < 64 - HL && x0 < W;
+    const bool full4 = x0 >= 0 && x0 + 3 < W;
+
+    float T[C + 1]; // taps by distance from the centre
+#pragma unroll
+    for (int a = 0; a <= C; a++) T[a] = t.tap[C - a];
+
+    // weights: full window (wave-uniform) and, at the column borders, this lane's four own weights
+    float cnt_full = t.tap[0];
+#pragma unroll
+    for (int k = 1; k < RING; k++) cnt_full = __fadd_rn(cnt_full, t.tap[k]);
+    const float inv_full = __fdiv_rn(1.0f, cnt_full);
+    float cnt_h[4], inv_h[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        cnt_h[j] = cnt_full;
+        inv_h[j] = inv_full;
+    }
+    if (COL_EDGE) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = x0 + j;
+            float c = 0.0f;
+#pragma unroll
+            for (int k = 0; k < RING; k++) {
+                int xx = x + k - C;
+                if (xx >= 0 && xx < W) c = __fadd_rn(c, t.tap[k]);
+            }
+            cnt_h[j] = (x >= 0 && x < W) ? c : 1.0f;
+            inv_h[j] = __fdiv_rn(1.0f, cnt_h[j]);
+        }
+    }
+
+    auto load_row = [&](int r) -> uint32_t {
+        if (ROW_EDGE && (r < 0 || r >= H)) return 0u; // wave-uniform
+        const uint8_t *p = jb.fimg + (size_t)r * W;
+        uint32_t v = 0u;
+        if (!COL_EDGE || full4) {
+            __builtin_memcpy(&v, p + x0, 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int x = x0 + j;
+                if (x >= 0 && x < W) v |= (uint32_t)p[x] << (8 * j);
+            }
+        }
+        return v;
+    };
+
+    float acc[RING][4]; // open column sums; slot = phase of the row that is the output's tap 0
+#pragma unroll
+    for (int s = 0; s < RING; s++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[s][i] = 0.0f;
+
+    auto step = [&](auto ph, int r, uint32_t cur) {
+        constexpr int PH = decltype(ph)::value; // (r - rfirst) mod RING
+        // ---- row pass of input row r ----------------------------------------------------------------
+        float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!ROW_EDGE || (r >= 0 && r < H)) {
+            const float v[4] = {(float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
+                                (float)(cur >> 24)};
+            float Q[4][C + 1];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int a = 0; a <= C; a++) Q[i][a] = __fmul_rn(v[i], T[a]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int d = -C; d <= C; d++) {
+                    const int e = i + d, a = d < 0 ? -d : d; // pixel e (relative to x0) at distance a
+                    float term;
+                    if (e >= 0 && e < 4) {
+                        term = Q[e][a];
+                    } else if (e < 0) {
+                        const int hop = (3 - e) / 4;
+                        term = lane_shr1(Q[e + 4 * hop][a]);
+                        if (hop == 2) term = lane_shr1(term);
+                    } else {
+                        const int hop = e / 4;
+                        term = lane_shl1(Q[e - 4 * hop][a]);
+                        if (hop == 2) term = lane_shl1(term);
+                    }
+                    s = (d == -C) ? term : __fadd_rn(s, term);
+                }
+                res[i] = FMA_DIV ? __fmaf_rn(s, fma_c, s) : div_by(s, cnt_h[i], inv_h[i]);
+            }
+        }
+
+        // ---- column pass: row r is tap k of output row r + C - k --------------------------------------
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float P[C + 1];
+#pragma unroll
+            for (int a = 0; a <= C; a++) P[a] = __fmul_rn(res[i], T[a]);
+            acc[PH][i] = P[C]; // k = 0 opens output row r + C
+#pragma unroll
+            for (int k = 1; k < RING; k++) {
+                const int slot = (PH + RING - k) % RING;
+                acc[slot][i] = __fadd_rn(acc[slot][i], P[k < C ? C - k : k - C]);
+            }
+        }
+
+        // ---- output row y = r - C just received its last tap -------------------------------------------
+        // Pin every open sum in a register HERE.  Nothing in this row uses the sums it has just advanced, so
+        // the optimiser otherwise sinks those adds (and their products) down to the row that finally stores
+        // them and carries 2C rows of row-pass results instead -- twice the registers, spills.
+#pragma unroll
+        for (int s = 0; s < RING; s++)
+            asm volatile("" : "+v"(acc[s][0]), "+v"(acc[s][1]), "+v"(acc[s][2]), "+v"(acc[s][3]));
+
+        // The quotient is taken unconditionally too (also for the 2C warm-up rows, whose sums are incomplete
+        // and never stored), so that no add can move into the store's branch.
+        const int y = r - C;
+        constexpr int DONE = (PH + 1) % RING;
+        const bool in_seg = y >= ybeg && y < yend; // wave-uniform
+        float cnt_v = cnt_full, inv_v = inv_full;
+        if (ROW_EDGE && in_seg && (y < C || y + C >= H)) { // top/bottom border rows renormalise
+            cnt_v = 0.0f;
+            for (int k = 0; k < RING; k++) {
+                int yy = y + k - C;
+                if (yy >= 0 && yy < H) cnt_v = __fadd_rn(cnt_v, t.tap[k]);
+            }
+            inv_v = __fdiv_rn(1.0f, cnt_v);
+        }
+        // float -> short truncates toward zero (src/utils.cpp:62)
+        auto quot = [&](float a) { return FMA_DIV ? __fmaf_rn(a, fma_c, a) : div_by(a, cnt_v, inv_v); };
+        const int o0 = (int)quot(acc[DONE][0]), o1 = (int)quot(acc[DONE][1]);
+        const int o2 = (int)quot(acc[DONE][2]), o3 = (int)quot(acc[DONE][3]);
+        uint2 pk;
+        pk.x = (uint32_t)(uint16_t)o0 | ((uint32_t)(uint16_t)o1 << 16);
+        pk.y = (uint32_t)(uint16_t)o2 | ((uint32_t)(uint16_t)o3 << 16);
+        asm volatile("" : "+v"(pk.x), "+v"(pk.y)); // materialise here, whatever the branch below does
+        if (in_seg && owner) {
+            int16_t *dst = jb.fout + (size_t)y * W + x0;
+            if (!COL_EDGE || full4) {
+                __builtin_memcpy(dst, &pk, 8);
+            } else {
+                dst[0] = (int16_t)pk.x;
+                if (x0 + 1 < W) dst[1] = (int16_t)(pk.x >> 16);
+                if (x0 + 2 < W) dst[2] = (int16_t)pk.y;
+            }
+        }
+    };
+
+    // Rows ybeg-C .. yend-1+C, count rounded up to a multiple of RING: accumulator slots and the prefetch
+    // registers (two rows ahead) then rotate by renaming only.
+    const int rfirst = ybeg - C;
+    const int rows = yend - ybeg + 2 * C;
+    const int rlast = rfirst + RING * ((rows + RING - 1) / RING) - 1;
+    uint32_t pf[RING];
+    pf[0] = load_row(rfirst);
+    pf[1] = load_row(rfirst + 1);
+    for (int r = rfirst; r <= rlast; r += RING) {
+        for_each_phase(
+            [&](auto ph) {
+                constexpr int PH = decltype(ph)::value;
+                pf[(PH + 2) % RING] = load_row(r + PH + 2);
+                step(ph, r + PH, pf[PH]);
+                // keep the scheduler from interleaving rows: one row's products are all the registers allow
+                __builtin_amdgcn_sched_barrier(0);
+            },
+            std::make_integer_sequence<int, RING>{});
+    }
+}
+
 } // namespace
+
+// Live state per lane: 4(2C+1) open sums + 4(C+1) products + ~30; without an occupancy target the scheduler
+// interleaves several rows' products and doubles that.
+template <int C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 5 ? 5 : 4)))
+void gauss_sym_kernel(const uint8_t *__restrict__ img, int16_t *__restrict__ out, int H, int W, int n_strips,
+                      int n_segs, int seg_rows, int total_waves, GaussTaps t, int use_fma_div, float fma_c)
+{
+    using K = MarchCfg<C>;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
+    if (wave >= total_waves) return;
+
+    const int s = wave % n_strips;
+    const int g = (wave / n_strips) % n_segs;
+    const int f = wave / (n_strips * n_segs);
+    GaussJob jb;
+    jb.lane = lane;
+    jb.H = H;
+    jb.W = W;
+    jb.ybeg = g * seg_rows;
+    jb.yend = min(H, jb.ybeg + seg_rows);
+    jb.x0 = s * K::SW + (lane - K::HL) * 4; // first of this lane's 4 columns (halo lanes may be outside)
+    jb.fimg = img + (size_t)f * H * W;
+    jb.fout = out + (size_t)f * H * W;
+
+    // the strip's lanes span columns [s*SW - 4HL, s*SW + SW + 4HL)
+    const bool col_edge = (s * K::SW - 4 * K::HL < 0) || (s * K::SW + K::SW + 4 * K::HL > W);
+    // rows loaded: ybeg-C .. yend-1+C, up to 2C more for the rounding to whole loop trips, +2 prefetched
+    const bool row_edge = (jb.ybeg - C < 0) || (jb.yend + C + K::RING >= H);
+    if (col_edge) {
+        if (row_edge)
+            gauss_sym_strip<C, true, true>(jb, t);
+        else
+            gauss_sym_strip<C, true, false>(jb, t);
+    } else {
+        if (row_edge)
+            gauss_sym_strip<C, false, true>(jb, t);
+        else if (use_fma_div)
+            gauss_sym_strip<C, false, false, true>(jb, t, fma_c);
+        else
+            gauss_sym_strip<C, false, false>(jb, t);
+    }
+}
 
 template <int C>
 __global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
@@ -328,6 +573,8 @@ int gaussian_fma_div_table(const unsigned (**table)[2])
 
 static bool fma_div_enabled = true; // A/B switch (canny_hip_ctx_set_option "gaussian_fma_div")
 void gaussian_set_fma_div(bool on) { fma_div_enabled = on; }
+static int march_variant = 0; // A/B switch "tune_gaussian_variant": 0 = symmetric-tap kernel, 1 = LDS ring kernel
+void gaussian_set_march_variant(int v) { march_variant = v; }
 
 // ---- exhaustive check of div_by against the IEEE divide (test hook) -----------------------------------
 // fma_c == 0: the 5-op div_by;  fma_c != 0 (passed as a bit pattern so that c = 0.0f is expressible through
@@ -368,13 +615,25 @@ static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, i
 {
     using K = MarchCfg<C>;
     int n_strips = (width + K::SW - 1) / K::SW;
-    // longest segments that still give the chip a few thousand waves
-    int seg = 256;
-    while (seg > 32 && (long long)n_frames * n_strips * ((height + seg - 1) / seg) < 16384) seg >>= 1;
+    // the symmetric-tap kernel needs tap[C-a] == tap[C+a] bit for bit (true for the reference's taps)
+    bool symmetric = march_variant == 0;
+    for (int a = 1; a <= C && symmetric; a++)
+        symmetric = std::memcmp(&taps.tap[C - a], &taps.tap[C + a], sizeof(float)) == 0;
+    // longest segments that still give the chip a few thousand waves; the symmetric kernel processes
+    // rows in trips of 2C+1, so its segments are sized to make seg + 2C a whole number of trips
+    auto seg_for = [&](int target) {
+        return symmetric ? std::max(1, (target + 2 * C + K::RING / 2) / K::RING) * K::RING - 2 * C : target;
+    };
+    int target = 256;
+    while (target > 32 &&
+           (long long)n_frames * n_strips * ((height + seg_for(target) - 1) / seg_for(target)) < 16384)
+        target >>= 1;
+    int seg = seg_for(target);
     int n_segs = (height + seg - 1) / seg;
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;
-    unsigned blocks = (unsigned)((waves + K::WPB - 1) / K::WPB);
+    const int wpb = symmetric ? 4 : K::WPB;
+    unsigned blocks = (unsigned)((waves + wpb - 1) / wpb);
     // full-window weight, summed exactly like the kernel (and the reference) does: ascending float adds
     volatile float s = taps.tap[0]; // volatile: keep the host compiler from re-associating / widening
     for (int k = 1; k < K::RING; k++) s = s + taps.tap[k];
@@ -388,8 +647,12 @@ static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, i
             use_fma = 1;
             std::memcpy(&fma_c, &e[1], sizeof(fma_c));
         }
-    hipLaunchKernelGGL(gauss_march_kernel<C>, dim3(blocks), dim3(K::WPB * 64), 0, stream, img, out, height, width,
-                       n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
+    if (symmetric)
+        hipLaunchKernelGGL(gauss_sym_kernel<C>, dim3(blocks), dim3(256), 0, stream, img, out, height, width, n_strips,
+                           n_segs, seg, (int)waves, taps, use_fma, fma_c);
+    else
+        hipLaunchKernelGGL(gauss_march_kernel<C>, dim3(blocks), dim3(K::WPB * 64), 0, stream, img, out, height, width,
+                           n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
     return hipGetLastError();
 }
 

@@ -61,15 +61,19 @@ def main():
         print(f"  {name:14s} median {med:.4f} ms  min {mn:.4f} ms   {alg / med / 1e6:.0f} GB/s  ({alg / med / 8e9 * 100:.1f}% of 8 TB/s)")
     ctx.set_option("tune_sobel_seg", 0)
 
-    gres = {0: [], 1: []}
+    gmodes = [(variant, fma) for variant in (0, 1) for fma in (0, 1)]
+    gres = {m: [] for m in gmodes}
     for _ in range(args.rounds):
-        for mode in (0, 1):
-            ctx.set_option("gaussian_fma_div", mode)
-            gres[mode].append(time_stage(lambda: ctx.dev_gaussian(d_img, args.sigma, H, W, F, d_sm),
-                                         capi.STAGE_GAUSSIAN))
+        for variant, fma in gmodes:
+            ctx.set_option("tune_gaussian_variant", variant)
+            ctx.set_option("gaussian_fma_div", fma)
+            gres[(variant, fma)].append(time_stage(lambda: ctx.dev_gaussian(d_img, args.sigma, H, W, F, d_sm),
+                                                   capi.STAGE_GAUSSIAN))
     ctx.set_option("gaussian_fma_div", 1)
-    for mode, name in ((0, "5-op division everywhere"), (1, "fma division in interior waves")):
-        g = gres[mode]
+    ctx.set_option("tune_gaussian_variant", 0)
+    for variant, fma in gmodes:
+        g = gres[(variant, fma)]
+        name = ("symmetric-tap" if variant == 0 else "LDS ring") + (", fma division" if fma else ", 5-op division")
         print(f"gaussian march [{name}]  median {statistics.median(g):.4f} ms  min {min(g):.4f} ms")
     ctx.dev_sobel_nms(d_sm, H, W, F, d_out)
     hy = {}

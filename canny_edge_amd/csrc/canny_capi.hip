@@ -70,6 +70,7 @@ struct canny_hip_ctx {
     int gaussian_path = 0;   // 0 auto, 1 generic, 2 march
     int sobel_nms_path = 0;  // 0 auto, 1 LDS tile, 2 march
     int tune_sobel_prefetch = 0, tune_sobel_seg = 0; // A/B knobs of the marching Sobel+NMS kernel
+    int fuse_classify = 1;   // canny(): Sobel+NMS emits the hysteresis bit-planes directly when it can
 
     // device workspaces
     DevBuf tmp_f32;   // generic Gaussian row-pass plane
@@ -234,6 +235,17 @@ int run_propagation(canny_hip_ctx *ctx, const HystGeom &g)
     return CANNY_HIP_OK;
 }
 
+// Second half of hysteresis, from filled bit-planes to the s16 edge map (every pixel of d_out is written).
+int propagate_and_finalize(canny_hip_ctx *ctx, const HystGeom &g, short *d_out, int hi)
+{
+    int rc = run_propagation(ctx, g);
+    if (rc) return rc;
+    StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_FINALIZE);
+    // reached pixels hold EDGE=255 and survive the final `< max_val -> 0` sweep only if 255 >= max_val
+    HIP_TRY(ctx, launch_hyst_finalize(d_out, (const uint64_t *)ctx->plane_s.p, g, 255 >= hi ? 255 : 0, ctx->stream));
+    return CANNY_HIP_OK;
+}
+
 int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int lo, int hi)
 {
     HystGeom g = make_hyst_geom(h, w, n);
@@ -246,14 +258,7 @@ int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int l
         HIP_TRY(ctx, launch_hyst_classify(d_cand, (uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p, g, lo, hi,
                                           flags + 1, ctx->stream));
     }
-    rc = run_propagation(ctx, g);
-    if (rc) return rc;
-    {
-        StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_FINALIZE);
-        // reached pixels hold EDGE=255 and survive the final `< max_val -> 0` sweep only if 255 >= max_val
-        HIP_TRY(ctx, launch_hyst_finalize(d_cand, (const uint64_t *)ctx->plane_s.p, g, 255 >= hi ? 255 : 0, ctx->stream));
-    }
-    return CANNY_HIP_OK;
+    return propagate_and_finalize(ctx, g, d_cand, hi);
 }
 
 // Fused Sobel+NMS on a smoothed plane in [0,255].
@@ -276,6 +281,20 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
     short *sm = (short *)ctx->smoothed.p;
     int rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm);
     if (rc) return rc;
+    if (ctx->fuse_classify && ctx->sobel_nms_path != 1 && sobel_nms_classify_supported(h, w, lo)) {
+        // Sobel+NMS writes the hysteresis bit-planes directly: the suppressed magnitudes never reach memory
+        // and the classify pass disappears (canny() does not return them; the stage API still does).
+        HystGeom g = make_hyst_geom(h, w, n);
+        if ((rc = ensure_hyst(ctx, g))) return rc;
+        uint64_t *S = (uint64_t *)ctx->plane_s.p, *C = (uint64_t *)ctx->plane_c.p;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->flags.p, 0, 2 * sizeof(unsigned), ctx->stream));
+        {
+            StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+            HIP_TRY(ctx, launch_hyst_zero_pad(S, C, g, ctx->stream));
+            HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, S, C, g, lo, hi, ctx->stream, ctx->tune_sobel_seg));
+        }
+        return propagate_and_finalize(ctx, g, d_edges, hi);
+    }
     if ((rc = dev_sobel_nms(ctx, sm, h, w, n, d_edges))) return rc;
     return dev_hysteresis(ctx, d_edges, h, w, n, lo, hi);
 }
@@ -397,6 +416,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "tune_sobel_prefetch") && (value == 0 || value == 2 || value == 5))
         ctx->tune_sobel_prefetch = value;
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
+    else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
     else if (!std::strcmp(name, "gaussian_fma_div") && value <= 1) gaussian_set_fma_div(value != 0); // process-wide
     else if (!std::strcmp(name, "tune_finalize_mode") && value <= 1) hyst_set_finalize_mode(value);   // process-wide
     else if (!std::strcmp(name, "tune_gaussian_variant") && value <= 1) gaussian_set_march_variant(value); // process-wide

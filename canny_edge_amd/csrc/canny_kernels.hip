@@ -758,6 +758,38 @@ hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t 
                            strong, conn, g, min_val, max_val, domain_flag);
     return hipGetLastError();
 }
+// Zeroes the parts of both planes that lie outside the image (rows >= H of the last tile row, columns >= W
+// of the last tile column).  The fused Sobel+NMS+classify kernel writes in-image plane bytes only; the
+// classify kernels above write whole tiles and do not need this.  Writes pad bytes only, so it may run
+// before, after or concurrently with the kernel that fills the image part.  Requires width % 8 == 0.
+__global__ __launch_bounds__(64) void hyst_zero_pad_kernel(uint64_t *__restrict__ strong, uint64_t *__restrict__ conn,
+                                                           HystGeom g)
+{
+    // grid: x = edge tile (0..tiles_x-1: last tile row, tiles_x..tiles_x+tiles_y-1: last tile column), y = frame
+    const int row = (int)threadIdx.x;
+    const int k = (int)blockIdx.x, f = (int)blockIdx.y;
+    const int tx = k < g.tiles_x ? k : g.tiles_x - 1;
+    const int ty = k < g.tiles_x ? g.tiles_y - 1 : k - g.tiles_x;
+    const size_t w = ((((size_t)f * g.tiles_y + ty) * g.tiles_x + tx) << 6) + row;
+    const int y = ty * kTile + row;
+    const int valid_px = min(kTile, g.width - tx * kTile); // in-image pixels of this word (multiple of 8)
+    if (y >= g.height) {
+        strong[w] = 0;
+        conn[w] = 0;
+    } else if (valid_px < kTile) {
+        uint8_t *sb = (uint8_t *)(strong + w), *cb = (uint8_t *)(conn + w);
+        for (int b = valid_px / 8; b < 8; b++) sb[b] = cb[b] = 0;
+    }
+}
+
+hipError_t launch_hyst_zero_pad(uint64_t *strong, uint64_t *conn, const HystGeom &g, hipStream_t stream)
+{
+    if (g.height % kTile == 0 && g.width % kTile == 0) return hipSuccess;
+    hipLaunchKernelGGL(hyst_zero_pad_kernel, dim3(g.tiles_x + g.tiles_y, g.n_frames), dim3(64), 0, stream, strong, conn,
+                       g);
+    return hipGetLastError();
+}
+
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *stamp, unsigned *last_change,
                                  int iter, const HystGeom &g, hipStream_t stream)
 {

@@ -69,6 +69,13 @@ __device__ __forceinline__ uint32_t pack_u16(int lo, int hi)
     return __builtin_bit_cast(uint32_t, (u16x2)__builtin_amdgcn_cvt_pk_u16((unsigned)lo, (unsigned)hi));
 }
 
+// bits = 2*bits + (a > b): v_cmp + v_addc.  (Written in C the compiler builds each bit with v_cndmask and
+// merges them with shifts and v_or3: three instructions per bit instead of two.)
+__device__ __forceinline__ void push_gt(unsigned &bits, int a, int b)
+{
+    asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
+}
+
 constexpr int SNM_PX = 8;           // pixels per lane
 constexpr int SNM_SW = 62 * SNM_PX; // output columns per strip
 constexpr int SNM_WPB = 4;          // waves per workgroup (independent of each other)
@@ -80,13 +87,22 @@ struct StripJob {
     const int16_t *fin;
     int16_t *fout;
     int H, W, ybeg, yend, x0, lane;
+    // PLANES only: this frame's hysteresis bit-planes (tile-major, see HystGeom) and the thresholds
+    uint8_t *pconn, *pstrong;
+    int tiles_x, lo1, hi1; // lo1 = min_val - 1, hi1 = max(min_val, max_val) - 1
 };
 
 // COL_EDGE: the strip touches column 0 or W-1 (lane-varying masks, partial lanes).
 // ROW_EDGE: the segment touches row 0 or H-1 (virtual rows, row clamp).  With both false the body is
 // straight-line code with unconditional 16-byte loads, so the compiler can keep two rows of loads in
 // flight behind counted s_waitcnt vmcnt(N).
-template <bool COL_EDGE, bool ROW_EDGE>
+// PLANES: instead of the s16 suppressed magnitudes, emit what hysteresis' classify step would derive from
+// them (src/utils.cpp:331-351): bit-plane `connectable` (v >= min_val) and `strong` (v >= min_val and
+// v >= max_val), one byte per lane and row.  Requires min_val >= 1 (then v >= min_val implies the pixel
+// survived NMS, so the threshold folds into the NMS comparison: mc > max(neighbour, min_val - 1)) and
+// W % 8 == 0 (a lane's 8 pixels are one plane byte).  The s16 plane is never written: 2 B/px of stores and
+// the whole classify pass (2 B/px of loads) disappear from the pipeline.
+template <bool COL_EDGE, bool ROW_EDGE, bool PLANES>
 __device__ __forceinline__ void march_strip(const StripJob &jb)
 {
     const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend;
@@ -224,14 +240,18 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
         const int y2 = r - 2;
         if (y2 >= ybeg && y2 < yend) {
             int res[8];
+            unsigned cbits = 0, sbits = 0;
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
+            for (int ee = 0; ee < 8; ee++) {
+                const int e = PLANES ? 7 - ee : ee; // planes: pixel 7 first, so that pixel e ends up in bit e
                 const int c = e + 1;
                 const int mc = M[m1][c];
-                const int n0 = max(M[m1][c - 1], M[m1][c + 1]);
-                const int n90 = max(M[m0][c], M[m2][c]);
-                const int n45 = max(M[m0][c + 1], M[m2][c - 1]);  // up-right, down-left
-                const int n135 = max(M[m0][c - 1], M[m2][c + 1]); // up-left, down-right
+                // PLANES: min_val - 1 rides along as the third operand of a v_max3_i32 -- no extra instruction
+                auto nmax = [&](int a, int b) { return PLANES ? max(max(a, b), jb.lo1) : max(a, b); };
+                const int n0 = nmax(M[m1][c - 1], M[m1][c + 1]);
+                const int n90 = nmax(M[m0][c], M[m2][c]);
+                const int n45 = nmax(M[m0][c + 1], M[m2][c - 1]);  // up-right, down-left
+                const int n135 = nmax(M[m0][c - 1], M[m2][c + 1]); // up-left, down-right
                 // Bin from two sign tests.  With X = gx^2-gy^2 and Y = 2 gx gy (the doubled angle) the bins are
                 // the quadrants of (X+Y, X-Y):  0: both >= 0,  90: both < 0,  45: X+Y >= 0 > X-Y,  135: the rest.
                 // P and X/2 are multiples of 1/2 and Q = X/2 + 1/4, so  X-Y >= 0  <=>  P <= Q  and
@@ -242,9 +262,22 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
                 const int na = v_ge0 ? n0 : n45;
                 const int nb = v_ge0 ? n135 : n90;
                 const int nsel = u_ge0 ? na : nb;
-                res[e] = (mc > nsel) ? mc : 0;
+                if (PLANES) {
+                    push_gt(cbits, mc, nsel);   // survived NMS and mc >= min_val
+                    push_gt(sbits, mc, jb.hi1); // mc >= max(min_val, max_val); ANDed with cbits below
+                } else {
+                    res[e] = (mc > nsel) ? mc : 0;
+                }
             }
-            if (owner) {
+            if (PLANES) {
+                if (owner) { // W % 8 == 0: an owner lane's 8 pixels are all inside the image
+                    const unsigned bx = (unsigned)x0 >> 3;
+                    const unsigned off = ((unsigned)(y2 >> 6) * (unsigned)jb.tiles_x + (bx >> 3)) * 512u +
+                                         (unsigned)(y2 & 63) * 8u + (bx & 7u);
+                    jb.pconn[off] = (uint8_t)cbits;
+                    jb.pstrong[off] = (uint8_t)(sbits & cbits);
+                }
+            } else if (owner) {
                 int16_t *dst = jb.fout + (size_t)y2 * W + x0;
                 if (!COL_EDGE || full8) {
                     uint4 v;
@@ -282,10 +315,16 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
 
 } // namespace
 
+struct PlaneArgs { // PLANES instantiation only
+    uint8_t *conn, *strong;
+    int tiles_x, tiles_y, lo1, hi1;
+};
+
+template <bool PLANES>
 __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int16_t *__restrict__ in,
                                                                        int16_t *__restrict__ out, int H, int W,
                                                                        int n_strips, int n_segs, int seg_rows,
-                                                                       int total_waves)
+                                                                       int total_waves, PlaneArgs pl)
 {
     // readfirstlane tells the compiler what it cannot prove: everything derived from the wave index is
     // wave-uniform, so rows, segments and border tests live in SGPRs and branch with s_cbranch.
@@ -302,21 +341,29 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
     jb.yend = min(H, jb.ybeg + seg_rows);
     jb.x0 = s * SNM_SW + (jb.lane - 1) * SNM_PX; // column of this lane's pixel 0
     jb.fin = in + (size_t)f * H * W;
-    jb.fout = out + (size_t)f * H * W;
+    jb.fout = PLANES ? nullptr : out + (size_t)f * H * W;
+    if (PLANES) {
+        const size_t frame_bytes = (size_t)pl.tiles_y * pl.tiles_x * 512;
+        jb.pconn = pl.conn + (size_t)f * frame_bytes;
+        jb.pstrong = pl.strong + (size_t)f * frame_bytes;
+        jb.tiles_x = pl.tiles_x;
+        jb.lo1 = pl.lo1;
+        jb.hi1 = pl.hi1;
+    }
     // first strip: column 0 and the out-of-image halo lane; last strip: column W-1 and columns >= W
     const bool col_edge = (s == 0) || ((s + 1) * SNM_SW + SNM_PX >= W);
     // rows touched: ybeg-2 .. (rounded-up last row) + 2 prefetched  <=  yend + 5
     const bool row_edge = (jb.ybeg < 2) || (jb.yend + 5 >= H);
     if (col_edge) {
         if (row_edge)
-            march_strip<true, true>(jb);
+            march_strip<true, true, PLANES>(jb);
         else
-            march_strip<true, false>(jb);
+            march_strip<true, false, PLANES>(jb);
     } else {
         if (row_edge)
-            march_strip<false, true>(jb);
+            march_strip<false, true, PLANES>(jb);
         else
-            march_strip<false, false>(jb);
+            march_strip<false, false, PLANES>(jb);
     }
 }
 
@@ -324,10 +371,9 @@ bool sobel_nms_march_supported(int height, int width) { return height >= 2 && wi
 
 // tune_seg: 0 = automatic, else rows per segment (A/B knob).  tune_prefetch is accepted for ABI stability of
 // the option and ignored: a 5-row prefetch distance measured identical to 2 rows (the kernel is VALU bound).
-hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
-                                  hipStream_t stream, int tune_prefetch, int tune_seg)
+static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const PlaneArgs *planes, int height, int width,
+                               int n_frames, hipStream_t stream, int tune_seg)
 {
-    (void)tune_prefetch;
     int n_strips = (width + SNM_SW - 1) / SNM_SW;
     int seg = 256;
     while (seg > 32 && (long long)n_frames * n_strips * ((height + seg - 1) / seg) < 16384) seg >>= 1;
@@ -336,9 +382,42 @@ hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int hei
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;
     unsigned blocks = (unsigned)((waves + SNM_WPB - 1) / SNM_WPB);
-    hipLaunchKernelGGL(sobel_nms_march_kernel, dim3(blocks), dim3(SNM_WPB * 64), 0, stream, smoothed, out, height,
-                       width, n_strips, n_segs, seg, (int)waves);
+    if (planes)
+        hipLaunchKernelGGL(sobel_nms_march_kernel<true>, dim3(blocks), dim3(SNM_WPB * 64), 0, stream, smoothed,
+                           (int16_t *)nullptr, height, width, n_strips, n_segs, seg, (int)waves, *planes);
+    else
+        hipLaunchKernelGGL(sobel_nms_march_kernel<false>, dim3(blocks), dim3(SNM_WPB * 64), 0, stream, smoothed, out,
+                           height, width, n_strips, n_segs, seg, (int)waves, PlaneArgs{});
     return hipGetLastError();
+}
+
+hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
+                                  hipStream_t stream, int tune_prefetch, int tune_seg)
+{
+    (void)tune_prefetch;
+    return launch_march(smoothed, out, nullptr, height, width, n_frames, stream, tune_seg);
+}
+
+bool sobel_nms_classify_supported(int height, int width, int min_val)
+{
+    return sobel_nms_march_supported(height, width) && width % 8 == 0 && min_val >= 1;
+}
+
+hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, uint64_t *strong, uint64_t *conn, const HystGeom &g,
+                                           int min_val, int max_val, hipStream_t stream, int tune_seg)
+{
+    if (!sobel_nms_classify_supported(g.height, g.width, min_val)) return hipErrorNotSupported;
+    // magnitudes are <= 1442, so thresholds beyond that all mean "never"; clamping keeps hi1 from overflowing
+    const int lo = min_val > 4096 ? 4096 : min_val;
+    const int hi = max_val > 4096 ? 4096 : max_val;
+    PlaneArgs pl;
+    pl.conn = (uint8_t *)conn;
+    pl.strong = (uint8_t *)strong;
+    pl.tiles_x = g.tiles_x;
+    pl.tiles_y = g.tiles_y;
+    pl.lo1 = lo - 1;
+    pl.hi1 = (hi > lo ? hi : lo) - 1;
+    return launch_march(smoothed, nullptr, &pl, g.height, g.width, g.n_frames, stream, tune_seg);
 }
 
 } // namespace canny

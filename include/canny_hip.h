@@ -92,6 +92,8 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "gaussian_path":  0 auto (default), 1 generic two-pass, 2 wave-marching (window <= 17)
  *   "sobel_nms_path": 0 auto (default), 1 LDS-tiled, 2 wave-marching
  *   "gaussian_fma_div": 1 (default) / 0 -- single-fma division by the full-window weight (process-wide)
+ *   "fuse_classify": 1 (default) / 0 -- canny(): the Sobel+NMS kernel writes the hysteresis bit-planes itself
+ *                    (used when width % 8 == 0 and min_val >= 1; otherwise the separate kernels run)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
  *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel, 1 LDS-ring marching kernel (process-wide)
  *   "tune_finalize_mode": 0 (default) row-major hysteresis finalize, 1 tile-patch finalize (process-wide) */

@@ -428,6 +428,37 @@ def test_sobel_nms_paths(hip, path):
                 assert bad.size == 0, (path, shape, seed, bad[:5].tolist())
 
 
+# canny() with the Sobel+NMS kernel writing the hysteresis bit-planes itself (fuse_classify=1, the default
+# when width % 8 == 0 and min_val >= 1) against the separate classify pass and against the oracle.  Shapes
+# cover tile padding in both directions, single-strip and multi-strip widths, one-tile images; thresholds
+# cover max < min, equal, unreachable, and min_val = 0 (which must fall back to the unfused kernels).
+FUSE_SHAPES = [(2, 8), (3, 16), (64, 64), (65, 72), (130, 496), (100, 504), (63, 520), (129, 1000), (200, 1488),
+               (70, 2048)]
+FUSE_THRESHOLDS = [(50, 150), (1, 1), (1, 5000), (100, 50), (20, 20), (255, 256), (0, 100), (300, 2000)]
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+@pytest.mark.parametrize("lo,hi", FUSE_THRESHOLDS)
+def test_canny_fused_classify(hip, fuse, lo, hi):
+    with hip.Context(0) as c:
+        c.set_option("fuse_classify", fuse)
+        for h, w in FUSE_SHAPES:
+            for n, seed in ((1, 3), (3, 4)):
+                frames = np.stack([_mixed(h, w, seed + 10 * i) if i != 1 else _noise(h, w, seed) for i in range(n)])
+                want = np.stack([oracle.canny(f, 1.0, lo, hi) for f in frames])
+                d_in, d_out = c.malloc(frames.nbytes), c.malloc(frames.nbytes * 2)
+                try:
+                    c.h2d(d_in, frames)
+                    c.dev_canny(d_in, 1.0, lo, hi, h, w, n, d_out)
+                    got = np.empty(frames.shape, np.int16)
+                    c.d2h(got, d_out)
+                finally:
+                    c.free(d_in)
+                    c.free(d_out)
+                bad = np.argwhere(got != want)
+                assert bad.size == 0, (fuse, lo, hi, h, w, n, bad[:5].tolist())
+
+
 @pytest.mark.parametrize("gpath,spath", [(1, 1), (2, 2)])
 def test_pipeline_paths_batched(hip, gpath, spath):
     frames = np.stack([_mixed(270, 520, 50 + i) for i in range(5)])

@@ -90,6 +90,27 @@ def main():
     for k, v in hy.items():
         print(f"{k:36s} median {statistics.median(v):.4f} ms  min {min(v):.4f} ms")
     print("hysteresis sweeps:", ctx.last_hysteresis_iterations)
+
+    # whole pipeline, with and without the Sobel+NMS kernel writing the bit-planes itself
+    import time
+    names = ["gaussian", "sobel_nms", "hyst_classify", "hyst_propagate", "hyst_finalize"]
+    pipe = {}
+    for _ in range(args.rounds):
+        for fuse in (0, 1):
+            ctx.set_option("fuse_classify", fuse)
+            ctx.profile_reset()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.dev_canny(d_img, args.sigma, 50, 150, H, W, F, d_out)
+            ctx.synchronize()
+            wall = (time.perf_counter() - t0) * 1e3
+            row = [ctx.profile_get(sid)[0] for sid in range(5)]
+            pipe.setdefault(fuse, []).append(row + [wall])
+    ctx.set_option("fuse_classify", 1)
+    for fuse in (0, 1):
+        med = [statistics.median(col) for col in zip(*pipe[fuse])]
+        parts = "  ".join(f"{n} {v:.3f}" for n, v in zip(names, med))
+        print(f"canny fuse_classify={fuse}: {parts}  | stages {sum(med[:5]):.3f} ms, wall {med[5]:.3f} ms")
     ctx.close()
 
 

@@ -272,6 +272,15 @@ __device__ __forceinline__ float lane_shl1(float v) // lane L <- lane L+1, lane 
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
+// A lane offset the optimiser cannot fold into a loop-invariant 64-bit VGPR pointer: the address stays
+// "uniform row base (SGPR pair) + 32-bit lane offset", which is global_load/store's saddr form; otherwise
+// every row pays a v_mad_u64_u32 and friends to add the row offset to a per-lane pointer.
+__device__ __forceinline__ uint32_t opaque_offset(uint32_t v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void for_each_phase(F &&f, std::integer_sequence<int, I...>)
 {
@@ -320,10 +329,10 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 
     auto load_row = [&](int r) -> uint32_t {
         if (ROW_EDGE && (r < 0 || r >= H)) return 0u; // wave-uniform
-        const uint8_t *p = jb.fimg + (size_t)r * W;
+        const uint8_t *p = jb.fimg + (size_t)r * W; // wave-uniform
         uint32_t v = 0u;
         if (!COL_EDGE || full4) {
-            __builtin_memcpy(&v, p + x0, 4);
+            __builtin_memcpy(&v, p + opaque_offset((uint32_t)x0), 4); // x0 >= 0 here
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -421,7 +430,9 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         pk.y = (uint32_t)(uint16_t)o2 | ((uint32_t)(uint16_t)o3 << 16);
         asm volatile("" : "+v"(pk.x), "+v"(pk.y)); // materialise here, whatever the branch below does
         if (in_seg && owner) {
-            int16_t *dst = jb.fout + (size_t)y * W + x0;
+            // owner lanes have x0 >= 0; byte offset so that no 64-bit shift is needed per lane
+            int16_t *dst = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(jb.fout + (size_t)y * W) +
+                                                       opaque_offset(2u * (uint32_t)x0));
             if (!COL_EDGE || full4) {
                 __builtin_memcpy(dst, &pk, 8);
             } else {
@@ -575,6 +586,8 @@ static bool fma_div_enabled = true; // A/B switch (canny_hip_ctx_set_option "gau
 void gaussian_set_fma_div(bool on) { fma_div_enabled = on; }
 static int march_variant = 0; // A/B switch "tune_gaussian_variant": 0 = symmetric-tap kernel, 1 = LDS ring kernel
 void gaussian_set_march_variant(int v) { march_variant = v; }
+static int tune_seg_target = 0; // A/B switch "tune_gaussian_seg": approximate rows per wave segment, 0 = automatic
+void gaussian_set_seg_target(int rows) { tune_seg_target = rows; }
 
 // ---- exhaustive check of div_by against the IEEE divide (test hook) -----------------------------------
 // fma_c == 0: the 5-op div_by;  fma_c != 0 (passed as a bit pattern so that c = 0.0f is expressible through
@@ -628,7 +641,7 @@ static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, i
     while (target > 32 &&
            (long long)n_frames * n_strips * ((height + seg_for(target) - 1) / seg_for(target)) < 16384)
         target >>= 1;
-    int seg = seg_for(target);
+    int seg = seg_for(tune_seg_target >= 8 ? tune_seg_target : target);
     int n_segs = (height + seg - 1) / seg;
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;

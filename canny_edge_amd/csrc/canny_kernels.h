@@ -55,6 +55,7 @@ int gaussian_fma_div_table(const unsigned (**table)[2]);
 void gaussian_set_fma_div(bool on);
 // A/B: 0 = symmetric-tap kernel (shared products, register accumulators; default), 1 = LDS-ring kernel.
 void gaussian_set_march_variant(int v);
+void gaussian_set_seg_target(int rows); // A/B: approximate rows per wave segment, 0 = automatic
 
 // ---- Sobel / NMS (src/utils.cpp:106-308) ----------------------------------------------------
 hipError_t launch_xy_gradient(const int16_t *img, int16_t *gx, int16_t *gy, int height, int width, int n_frames,

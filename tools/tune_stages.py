@@ -75,6 +75,16 @@ def main():
         g = gres[(variant, fma)]
         name = ("symmetric-tap" if variant == 0 else "LDS ring") + (", fma division" if fma else ", 5-op division")
         print(f"gaussian march [{name}]  median {statistics.median(g):.4f} ms  min {min(g):.4f} ms")
+    segs = (0, 64, 100, 188, 265, 441)
+    sres = {s: [] for s in segs}
+    for _ in range(args.rounds):
+        for s in segs:
+            ctx.set_option("tune_gaussian_seg", s)
+            sres[s].append(time_stage(lambda: ctx.dev_gaussian(d_img, args.sigma, H, W, F, d_sm), capi.STAGE_GAUSSIAN))
+    ctx.set_option("tune_gaussian_seg", 0)
+    for s in segs:
+        print(f"gaussian symmetric-tap, segment target {s or 'auto':>4}: median {statistics.median(sres[s]):.4f} ms  "
+              f"min {min(sres[s]):.4f} ms")
     ctx.dev_sobel_nms(d_sm, H, W, F, d_out)
     hy = {}
     for _ in range(args.rounds):

@@ -14,8 +14,12 @@ Workload (BASELINE.json configs[1]): 3840x2160 gray, sigma 1.4, thresholds 50/15
 1 GB s16 per intermediate plane) is far beyond the 256 MB Infinity Cache.
 
 The JSON line also carries
-  roofline     -- fused Sobel+NMS kernel: algorithmic bytes (4 B/px: s16 in + s16 out) / average launch
-                  time measured with HIP events on the launch stream inside the timed region, vs 8 TB/s
+  roofline     -- the Sobel+NMS kernel of the timed region: algorithmic bytes / average launch time measured
+                  with HIP events on the launch stream inside the timed region, vs 8 TB/s.  canny() runs it
+                  with the hysteresis threshold-classify step inside (2 B/px s16 in + 0.25 B/px bit-planes
+                  out); `roofline_sobel_nms_s16` is the stage-API form SURVEY.md 8(d) prices at 4 B/px (s16 in,
+                  s16 out), timed the same way on the same batch right after the timed region;
+                  `roofline_other_kernels` prices the other kernels of the step the same way
   cpu_baseline -- the CPU oracle (a faithful single-thread restatement of the reference's utils.cpp;
                   the reference itself cannot be compiled here) timed on a bounded sample, rank 0, N=1
 torch is used only for device memory, the stream and torch.distributed.
@@ -45,6 +49,8 @@ def parse():
     ap.add_argument("--min-val", type=int, default=50)
     ap.add_argument("--max-val", type=int, default=150)
     ap.add_argument("--cpu-frames", type=int, default=10, help="frames the CPU baseline times (rank 0, N=1)")
+    ap.add_argument("--fuse-classify", type=int, default=1, choices=(0, 1),
+                    help="0: canny() runs Sobel+NMS and the hysteresis classify pass as separate kernels (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the pre-timing parity spot check")
     return ap.parse_args()
@@ -107,6 +113,7 @@ def main():
     ctx = capi.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    ctx.set_option("fuse_classify", args.fuse_classify)
 
     def step():
         ctx.dev_canny(d_img.data_ptr(), args.sigma, args.min_val, args.max_val, H, W, F, d_edges.data_ptr())
@@ -151,26 +158,71 @@ def main():
     px_per_step = F * H * W
     value = sharding.aggregate_throughput(px_per_step * args.steps, world, elapsed) / 1e6
 
-    sn_ms, sn_n = stages["sobel_nms"]["ms_per_step"], stages["sobel_nms"]["launch_groups"]
-    sn_avg_s = sn_ms * 1e-3  # one launch per step covers the whole batch
-    alg_bytes = 4.0 * px_per_step
-    achieved = alg_bytes / sn_avg_s / 1e9 if sn_avg_s > 0 else 0.0
-    traffic = None
+    # ---- roofline -------------------------------------------------------------------------------------
+    # PMC-measured HBM bytes per launch (profiles/traffic_sobel_nms.json, made by tools/pmc_passes.sh +
+    # tools/pmc_summary.py on this same workload); null when the file does not cover this shape.
+    measured = {}
     tpath = os.path.join(ROOT, "profiles", "traffic_sobel_nms.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("frames") == F and tj.get("height") == H and tj.get("width") == W:
-                traffic = tj.get("hbm_bytes_per_launch")
+                measured = tj.get("kernels", {})
         except Exception:
-            traffic = None
-    roofline = {
-        "kernel": "fused Sobel+NMS (s16 smoothed in, s16 suppressed magnitude out)",
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(sn_ms, 4),
-        "launches_timed": sn_n,
+            measured = {}
+
+    def roof(kernel, what, bytes_per_px, ms, launches, extra=None):
+        alg = bytes_per_px * px_per_step
+        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        r = {"kernel": what, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured.get(kernel, {}).get("hbm_bytes_per_launch"),
+             "algorithmic_bytes_per_px": bytes_per_px, "algorithmic_bytes_per_launch": int(alg),
+             "avg_launch_ms": round(ms, 4), "launches_timed": launches}
+        if extra:
+            r.update(extra)
+        return r
+
+    fused = stages["hyst_classify"]["launch_groups"] == 0  # canny() ran Sobel+NMS with the classify step inside
+    sn_ms, sn_n = stages["sobel_nms"]["ms_per_step"], stages["sobel_nms"]["launch_groups"]
+    if fused:
+        # The pass the pipeline actually runs: s16 smoothed in (2 B/px), two 1-bit planes out (2/8 B/px).  It
+        # is bound by VALU issue, not by HBM (DESIGN.md "Kernels"): ~25 VALU instructions per pixel.
+        roofline = roof("sobel_nms_classify",
+                        "fused Sobel+NMS+threshold-classify (s16 smoothed in, strong/connectable bit-planes out)",
+                        2.25, sn_ms, sn_n, {"limiter": "VALU issue (see DESIGN.md); HBM traffic was cut instead"})
+    else:
+        roofline = roof("sobel_nms", "fused Sobel+NMS (s16 smoothed in, s16 suppressed magnitude out)", 4.0,
+                        sn_ms, sn_n)
+
+    # SURVEY.md 8(d) prices "the fused Sobel+NMS pass" at 4 B/px (s16 in, s16 out).  That kernel is what the
+    # stage API (nonmaximalSuppression after sobelOperator) runs; time it on the same resident batch, same
+    # HIP-event mechanism, right after the timed region, so that both figures come from one run.
+    d_sm = torch.empty((F, H, W), dtype=torch.int16, device=dev)
+    ctx.dev_gaussian(d_img.data_ptr(), args.sigma, H, W, F, d_sm.data_ptr())
+    ctx.dev_sobel_nms(d_sm.data_ptr(), H, W, F, d_edges.data_ptr())
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(args.steps):
+        ctx.dev_sobel_nms(d_sm.data_ptr(), H, W, F, d_edges.data_ptr())
+    torch.cuda.synchronize()
+    ms16, n16 = ctx.profile_get(capi.STAGE_SOBEL_NMS)
+    ctx.profile_enable(False)
+    del d_sm
+    roofline_s16 = roof("sobel_nms", "fused Sobel+NMS, stage-API form (s16 smoothed in, s16 suppressed magnitude out)",
+                        4.0, ms16 / max(1, n16), n16, {"timed": "after the timed region, same batch, HIP events"})
+
+    per_kernel = {
+        "gaussian": roof("gaussian", "separable Gaussian, rows+columns in one kernel (u8 in, s16 out)", 3.0,
+                         stages["gaussian"]["ms_per_step"], stages["gaussian"]["launch_groups"],
+                         {"limiter": "VALU issue: separately rounded f32 mul/add chains (bit-exactness)"}),
+        "hyst_finalize": roof("hyst_finalize", "hysteresis finalize (1-bit plane in, s16 edge map out)", 2.125,
+                              stages["hyst_finalize"]["ms_per_step"], stages["hyst_finalize"]["launch_groups"]),
     }
+    if not fused:
+        per_kernel["hyst_classify"] = roof("hyst_classify", "hysteresis classify (s16 in, two 1-bit planes out)", 2.25,
+                                           stages["hyst_classify"]["ms_per_step"],
+                                           stages["hyst_classify"]["launch_groups"])
 
     out = {
         "metric": "Mpixels/s end-to-end Canny (4K gray); % HBM roofline on Sobel+NMS",
@@ -183,6 +235,8 @@ def main():
                    "frames_per_gpu": F, "height": H, "width": W, "sigma": args.sigma,
                    "sharding": "independent frames per GPU, no collective"},
         "roofline": roofline,
+        "roofline_sobel_nms_s16": roofline_s16,
+        "roofline_other_kernels": per_kernel,
         "stages": stages,
         "hysteresis_sweeps": hyst_sweeps,
         "parity_checked": parity,

@@ -62,11 +62,15 @@ __device__ __forceinline__ uint32_t from_right(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
-// two non-negative ints (< 65536) -> packed u16 pair, one v_cvt_pk_u16_u32
-__device__ __forceinline__ uint32_t pack_u16(int lo, int hi)
+// pair.hi16 = (a > b) ? a : 0, low half untouched: the SDWA form of v_cndmask writes the kept magnitude
+// straight into the upper half of the output pair, which saves the v_cvt_pk_u16_u32 per pixel pair.
+__device__ __forceinline__ void keep_gt_hi(uint32_t &pair, int a, int b, int zero)
 {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(uint32_t, (u16x2)__builtin_amdgcn_cvt_pk_u16((unsigned)lo, (unsigned)hi));
+    asm("v_cmp_gt_i32 vcc, %1, %2\n\t"
+        "v_cndmask_b32_sdwa %0, %3, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(pair)
+        : "v"(a), "v"(b), "v"(zero)
+        : "vcc");
 }
 
 // bits = 2*bits + (a > b): v_cmp + v_addc.  (Written in C the compiler builds each bit with v_cndmask and
@@ -239,7 +243,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
         // ---- NMS for row y2 = r-2 ---------------------------------------------------------------
         const int y2 = r - 2;
         if (y2 >= ybeg && y2 < yend) {
-            int res[8];
+            uint32_t outp[4] = {0u, 0u, 0u, 0u}; // suppressed magnitudes as s16 pairs (pixel 2i, pixel 2i+1)
             unsigned cbits = 0, sbits = 0;
 #pragma unroll
             for (int ee = 0; ee < 8; ee++) {
@@ -265,8 +269,10 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
                 if (PLANES) {
                     push_gt(cbits, mc, nsel);   // survived NMS and mc >= min_val
                     push_gt(sbits, mc, jb.hi1); // mc >= max(min_val, max_val); ANDed with cbits below
+                } else if ((e & 1) == 0) {
+                    outp[e >> 1] = (uint32_t)((mc > nsel) ? mc : 0); // magnitudes are < 65536: upper half zero
                 } else {
-                    res[e] = (mc > nsel) ? mc : 0;
+                    keep_gt_hi(outp[e >> 1], mc, nsel, 0);
                 }
             }
             if (PLANES) {
@@ -280,16 +286,12 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
             } else if (owner) {
                 int16_t *dst = jb.fout + (size_t)y2 * W + x0;
                 if (!COL_EDGE || full8) {
-                    uint4 v;
-                    v.x = pack_u16(res[0], res[1]);
-                    v.y = pack_u16(res[2], res[3]);
-                    v.z = pack_u16(res[4], res[5]);
-                    v.w = pack_u16(res[6], res[7]);
+                    const uint4 v = make_uint4(outp[0], outp[1], outp[2], outp[3]);
                     __builtin_memcpy(dst, &v, 16);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; e++)
-                        if (x0 + e < W) dst[e] = (int16_t)res[e];
+                        if (x0 + e < W) dst[e] = (int16_t)(outp[e >> 1] >> (16 * (e & 1)));
                 }
             }
         }

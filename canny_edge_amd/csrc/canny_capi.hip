@@ -78,6 +78,7 @@ struct canny_hip_ctx {
     DevBuf plane_s, plane_c, stamps, flags; // hysteresis bit-planes / scheduling words
     DevBuf io[4];     // staging for the host-pointer stage functions
     unsigned *host_flags = nullptr; // pinned, 2 words
+    hipEvent_t flag_event = nullptr; // recorded behind the copy of the flags to host_flags
 
     // profiling
     bool prof = false;
@@ -202,22 +203,36 @@ int ensure_hyst(canny_hip_ctx *ctx, const HystGeom &g)
     HIP_TRY(ctx, ctx->stamps.ensure(hyst_sched_words(g) * sizeof(unsigned)));
     HIP_TRY(ctx, ctx->flags.ensure(2 * sizeof(unsigned)));
     if (!ctx->host_flags) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->host_flags, 2 * sizeof(unsigned)));
+    if (!ctx->flag_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->flag_event, hipEventDisableTiming));
     return CANNY_HIP_OK;
 }
 
-// Runs propagation sweeps until no tile was re-stamped.  flags[0] = last_change, flags[1] = domain.
-int run_propagation(canny_hip_ctx *ctx, const HystGeom &g)
+// First launch of a hysteresis call: clears the scheduling words and the flags (flags[0] = last_change,
+// flags[1] = domain) and, for planes filled by the Sobel+NMS kernel, the tile padding.
+int prepare_hyst(canny_hip_ctx *ctx, const HystGeom &g, bool zero_pad)
+{
+    HIP_TRY(ctx, launch_hyst_prepare((uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p, g, zero_pad,
+                                     (unsigned *)ctx->stamps.p, (unsigned *)ctx->flags.p, ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+// Runs propagation sweeps until no tile was re-stamped, then (or meanwhile) the consumer of the strong plane.
+// Sweeps are launched eight at a time before the host looks at the flag: natural images converge in 5-10
+// sweeps, and a sweep with an empty queue costs ~4 us while a host round trip costs ~25 us.
+// speculative: the consumer is a pure function of the strong plane that overwrites all of its output (the
+// finalize kernel), so it is launched right behind each chunk of sweeps, BEFORE the host has seen the flag;
+// the host waits on an event recorded behind the flag copy only, and the GPU never idles for the round trip.
+// If the flag says "not converged" (rare) the consumer simply runs again behind the next chunk.
+template <class Consumer>
+int run_propagation(canny_hip_ctx *ctx, const HystGeom &g, bool speculative, Consumer &&consumer)
 {
     uint64_t *S = (uint64_t *)ctx->plane_s.p;
     const uint64_t *C = (const uint64_t *)ctx->plane_c.p;
     unsigned *stamp = (unsigned *)ctx->stamps.p; // tile stamps + work queues + queue counters
     unsigned *flags = (unsigned *)ctx->flags.p;
-    HIP_TRY(ctx, hipMemsetAsync(stamp, 0, hyst_sched_words(g) * sizeof(unsigned), ctx->stream));
     const int kMaxSweeps = 1 << 22;
-    int iter = 0;
+    int iter = 0, rc;
     for (;;) {
-        // Sweeps are launched eight at a time before the host looks at the flag: natural images converge in
-        // 5-10 sweeps, and a sweep with an empty queue costs ~3 us while a host round trip costs ~25 us.
         const int chunk = 8;
         {
             StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_PROPAGATE);
@@ -226,24 +241,27 @@ int run_propagation(canny_hip_ctx *ctx, const HystGeom &g)
         }
         iter += chunk;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->host_flags, flags, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->flag_event, ctx->stream));
+        if (speculative && (rc = consumer())) return rc;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->flag_event));
         if (ctx->host_flags[1]) return CANNY_HIP_ERR_DOMAIN;
         if (ctx->host_flags[0] != (unsigned)iter) break; // nothing scheduled for sweep `iter`
         if (iter >= kMaxSweeps) return CANNY_HIP_ERR_NO_CONVERGE;
     }
     ctx->last_hyst_iters = (int)ctx->host_flags[0] + 1;
-    return CANNY_HIP_OK;
+    return speculative ? CANNY_HIP_OK : consumer();
 }
 
 // Second half of hysteresis, from filled bit-planes to the s16 edge map (every pixel of d_out is written).
 int propagate_and_finalize(canny_hip_ctx *ctx, const HystGeom &g, short *d_out, int hi)
 {
-    int rc = run_propagation(ctx, g);
-    if (rc) return rc;
-    StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_FINALIZE);
-    // reached pixels hold EDGE=255 and survive the final `< max_val -> 0` sweep only if 255 >= max_val
-    HIP_TRY(ctx, launch_hyst_finalize(d_out, (const uint64_t *)ctx->plane_s.p, g, 255 >= hi ? 255 : 0, ctx->stream));
-    return CANNY_HIP_OK;
+    return run_propagation(ctx, g, /*speculative=*/true, [&]() -> int {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_FINALIZE);
+        // reached pixels hold EDGE=255 and survive the final `< max_val -> 0` sweep only if 255 >= max_val
+        HIP_TRY(ctx, launch_hyst_finalize(d_out, (const uint64_t *)ctx->plane_s.p, g, 255 >= hi ? 255 : 0,
+                                          ctx->stream));
+        return CANNY_HIP_OK;
+    });
 }
 
 int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int lo, int hi)
@@ -251,12 +269,11 @@ int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int l
     HystGeom g = make_hyst_geom(h, w, n);
     int rc = ensure_hyst(ctx, g);
     if (rc) return rc;
-    unsigned *flags = (unsigned *)ctx->flags.p;
-    HIP_TRY(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), ctx->stream));
+    if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/false))) return rc; // the classify kernels write whole tiles
     {
         StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_CLASSIFY);
         HIP_TRY(ctx, launch_hyst_classify(d_cand, (uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p, g, lo, hi,
-                                          flags + 1, ctx->stream));
+                                          (unsigned *)ctx->flags.p + 1, ctx->stream));
     }
     return propagate_and_finalize(ctx, g, d_cand, hi);
 }
@@ -287,10 +304,9 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
         HystGeom g = make_hyst_geom(h, w, n);
         if ((rc = ensure_hyst(ctx, g))) return rc;
         uint64_t *S = (uint64_t *)ctx->plane_s.p, *C = (uint64_t *)ctx->plane_c.p;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->flags.p, 0, 2 * sizeof(unsigned), ctx->stream));
+        if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc; // the kernel below writes in-image bytes only
         {
             StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
-            HIP_TRY(ctx, launch_hyst_zero_pad(S, C, g, ctx->stream));
             HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, S, C, g, lo, hi, ctx->stream, ctx->tune_sobel_seg));
         }
         return propagate_and_finalize(ctx, g, d_edges, hi);
@@ -386,6 +402,7 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
     ctx->flags.release();
     for (auto &b : ctx->io) b.release();
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
+    if (ctx->flag_event) (void)hipEventDestroy(ctx->flag_event);
     for (auto &v : ctx->pending)
         for (auto &e : v) {
             (void)hipEventDestroy(e.a);
@@ -595,14 +612,17 @@ int canny_hip_find_edge_pixels(canny_hip_ctx *ctx, short *edge_candidates, unsig
     if ((rc = ensure_hyst(ctx, g))) return rc;
     if ((rc = h2d(ctx, ctx->io[0], edge_candidates, n * 2))) return rc;
     if ((rc = h2d(ctx, ctx->io[1], visited, n))) return rc;
-    unsigned *flags = (unsigned *)ctx->flags.p;
-    HIP_TRY(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(unsigned), ctx->stream));
+    if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/false))) return rc;
     HIP_TRY(ctx, launch_fep_classify((const int16_t *)ctx->io[0].p, (const uint8_t *)ctx->io[1].p,
                                      (uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p, g, start, min_val,
                                      ctx->stream));
-    if ((rc = run_propagation(ctx, g))) return rc;
-    HIP_TRY(ctx, launch_fep_finalize((int16_t *)ctx->io[0].p, (uint8_t *)ctx->io[1].p, (const uint64_t *)ctx->plane_s.p,
-                                     g, start, min_val, ctx->stream));
+    // fep_finalize updates its inputs in place, so it runs once, after convergence (not speculatively)
+    rc = run_propagation(ctx, g, /*speculative=*/false, [&]() -> int {
+        HIP_TRY(ctx, launch_fep_finalize((int16_t *)ctx->io[0].p, (uint8_t *)ctx->io[1].p,
+                                         (const uint64_t *)ctx->plane_s.p, g, start, min_val, ctx->stream));
+        return CANNY_HIP_OK;
+    });
+    if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(edge_candidates, ctx->io[0].p, n * 2, hipMemcpyDeviceToHost, ctx->stream));
     return d2h_sync(ctx, visited, ctx->io[1].p, n);
 }

@@ -75,7 +75,7 @@ hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int hei
 
 // Fused Sobel+NMS+classify: the same marching kernel, but instead of the s16 suppressed magnitudes it
 // writes the two hysteresis bit-planes that launch_hyst_classify would derive from them (in-image bytes
-// only: pair it with launch_hyst_zero_pad).  Needs width % 8 == 0 and min_val >= 1.
+// only: pair it with launch_hyst_prepare(..., zero_pad = true)).  Needs width % 8 == 0 and min_val >= 1.
 bool sobel_nms_classify_supported(int height, int width, int min_val);
 hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, uint64_t *strong, uint64_t *conn, const HystGeom &g,
                                            int min_val, int max_val, hipStream_t stream, int tune_seg = 0);
@@ -83,11 +83,14 @@ hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, uint64_t *st
 // ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
 hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,
                                 int max_val, unsigned *domain_flag, hipStream_t stream);
-// Zeroes the plane bits outside the image (tile padding); no-op when both dimensions are multiples of 64.
-hipError_t launch_hyst_zero_pad(uint64_t *strong, uint64_t *conn, const HystGeom &g, hipStream_t stream);
 // One propagation sweep (`iter` = 0,1,2,...).  sched holds hyst_sched_words(g) words (tile stamps, two
 // work queues, three queue counters) and, like the single word last_change, must be zero before sweep 0.
 inline size_t hyst_sched_words(const HystGeom &g) { return 3 * (size_t)g.tiles() + 4; }
+// First launch of a hysteresis call: zeroes sched (hyst_sched_words(g) words) and flags[0..1] (last_change,
+// domain) and, if zero_pad, the plane bits outside the image (tile padding; needed when the planes are filled
+// by launch_sobel_nms_classify_march, which writes in-image bytes only; requires width % 8 == 0).
+hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom &g, bool zero_pad, unsigned *sched,
+                               unsigned *flags, hipStream_t stream);
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
                                  int iter, const HystGeom &g, hipStream_t stream);
 hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const HystGeom &g, int edge_value,

@@ -443,6 +443,9 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
     const size_t rowstep = (size_t)g.tiles_x * kTile; // words between vertically adjacent tiles
 
     const uint64_t c = conn[base + lane];
+    // Only connectable pixels can ever be added, so a tile without a single one (flat regions: most tiles of a
+    // natural frame) cannot change: leave before the strong plane and the nine halo loads are touched.
+    if (!__any(c != 0)) return;
     const uint64_t s0 = strong[base + lane];
     // halo from the eight neighbouring tiles (read once per sweep; a change made there during
     // this sweep re-stamps us for the next one)
@@ -758,35 +761,52 @@ hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t 
                            strong, conn, g, min_val, max_val, domain_flag);
     return hipGetLastError();
 }
-// Zeroes the parts of both planes that lie outside the image (rows >= H of the last tile row, columns >= W
-// of the last tile column).  The fused Sobel+NMS+classify kernel writes in-image plane bytes only; the
+// Start of every hysteresis call.  With zero_pad it zeroes the parts of both planes that lie outside the image
+// (rows >= H of the last tile row, columns >= W of the last tile column).  The fused Sobel+NMS+classify kernel writes in-image plane bytes only; the
 // classify kernels above write whole tiles and do not need this.  Writes pad bytes only, so it may run
 // before, after or concurrently with the kernel that fills the image part.  Requires width % 8 == 0.
-__global__ __launch_bounds__(64) void hyst_zero_pad_kernel(uint64_t *__restrict__ strong, uint64_t *__restrict__ conn,
-                                                           HystGeom g)
+// The same kernel clears the scheduling words and the two flag words of the propagation (one launch instead
+// of two memsets and a kernel: each of those costs ~10 us of launch gap on the stream).
+__global__ __launch_bounds__(256) void hyst_prepare_kernel(uint64_t *__restrict__ strong, uint64_t *__restrict__ conn,
+                                                           HystGeom g, int pad_waves, unsigned *__restrict__ sched,
+                                                           unsigned n_sched, unsigned *__restrict__ flags)
 {
-    // grid: x = edge tile (0..tiles_x-1: last tile row, tiles_x..tiles_x+tiles_y-1: last tile column), y = frame
-    const int row = (int)threadIdx.x;
-    const int k = (int)blockIdx.x, f = (int)blockIdx.y;
-    const int tx = k < g.tiles_x ? k : g.tiles_x - 1;
-    const int ty = k < g.tiles_x ? g.tiles_y - 1 : k - g.tiles_x;
-    const size_t w = ((((size_t)f * g.tiles_y + ty) * g.tiles_x + tx) << 6) + row;
-    const int y = ty * kTile + row;
-    const int valid_px = min(kTile, g.width - tx * kTile); // in-image pixels of this word (multiple of 8)
-    if (y >= g.height) {
-        strong[w] = 0;
-        conn[w] = 0;
-    } else if (valid_px < kTile) {
-        uint8_t *sb = (uint8_t *)(strong + w), *cb = (uint8_t *)(conn + w);
-        for (int b = valid_px / 8; b < 8; b++) sb[b] = cb[b] = 0;
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (wave < pad_waves) {
+        // one wave per edge tile and frame (k < tiles_x: last tile row, else: last tile column), lane = row
+        const int per_frame = g.tiles_x + g.tiles_y;
+        const int f = wave / per_frame, k = wave - f * per_frame;
+        const int tx = k < g.tiles_x ? k : g.tiles_x - 1;
+        const int ty = k < g.tiles_x ? g.tiles_y - 1 : k - g.tiles_x;
+        const size_t w = ((((size_t)f * g.tiles_y + ty) * g.tiles_x + tx) << 6) + lane;
+        const int y = ty * kTile + lane;
+        const int valid_px = min(kTile, g.width - tx * kTile); // in-image pixels of this word (multiple of 8)
+        if (y >= g.height) {
+            strong[w] = 0;
+            conn[w] = 0;
+        } else if (valid_px < kTile) {
+            uint8_t *sb = (uint8_t *)(strong + w), *cb = (uint8_t *)(conn + w);
+            for (int b = valid_px / 8; b < 8; b++) sb[b] = cb[b] = 0;
+        }
+        return;
     }
+    const size_t i0 = ((size_t)(wave - pad_waves) * 64 + lane) * 4;
+    for (int j = 0; j < 4; j++)
+        if (i0 + j < n_sched) sched[i0 + j] = 0u;
+    if (wave == pad_waves && lane == 0) flags[0] = flags[1] = 0u;
 }
 
-hipError_t launch_hyst_zero_pad(uint64_t *strong, uint64_t *conn, const HystGeom &g, hipStream_t stream)
+hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom &g, bool zero_pad, unsigned *sched,
+                               unsigned *flags, hipStream_t stream)
 {
-    if (g.height % kTile == 0 && g.width % kTile == 0) return hipSuccess;
-    hipLaunchKernelGGL(hyst_zero_pad_kernel, dim3(g.tiles_x + g.tiles_y, g.n_frames), dim3(64), 0, stream, strong, conn,
-                       g);
+    const bool pad = zero_pad && (g.height % kTile != 0 || g.width % kTile != 0);
+    const long long pad_waves = pad ? (long long)(g.tiles_x + g.tiles_y) * g.n_frames : 0;
+    const size_t n_sched = hyst_sched_words(g);
+    const long long waves = pad_waves + (long long)((n_sched + 255) / 256);
+    if (pad_waves > 0x3fffffffLL || n_sched > 0xffffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(hyst_prepare_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, strong, conn, g,
+                       (int)pad_waves, sched, (unsigned)n_sched, flags);
     return hipGetLastError();
 }
 

@@ -287,8 +287,14 @@ __device__ __forceinline__ void for_each_phase(F &&f, std::integer_sequence<int,
     (f(IC<I>{}), ...);
 }
 
-template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV = false>
-__device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussTaps &t, float fma_c = 0.0f)
+// lut (may be null): (C+1) x 256 floats in LDS, lut[a*256 + v] = RN(float(v) * tap[C-a]), filled by the kernel.
+// With it the row pass LOOKS UP its products (the input is 8 bits, so each tap has only 256 of them) instead
+// of multiplying: ds_read_b32 issues on the LDS port beside the VALU work of other waves, and this kernel is
+// bound by VALU issue.  The lookups of one instruction hit 64 pixels 4 columns apart -- nearly equal values,
+// i.e. neighbouring or identical words: few bank conflicts on natural images.
+template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV, bool USE_LUT>
+__device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussTaps &t, const float *lut,
+                                                float fma_c = 0.0f)
 {
     static_assert(!FMA_DIV || (!COL_EDGE && !ROW_EDGE), "FMA_DIV needs a single wave-uniform divisor");
     constexpr int HL = MarchCfg<C>::HL, RING = 2 * C + 1;
@@ -354,13 +360,22 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         // ---- row pass of input row r ----------------------------------------------------------------
         float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (!ROW_EDGE || (r >= 0 && r < H)) {
-            const float v[4] = {(float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
-                                (float)(cur >> 24)};
             float Q[4][C + 1];
+            if (USE_LUT) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+                for (int i = 0; i < 4; i++) {
+                    const float *row = lut + ((cur >> (8 * i)) & 0xffu);
 #pragma unroll
-                for (int a = 0; a <= C; a++) Q[i][a] = __fmul_rn(v[i], T[a]);
+                    for (int a = 0; a <= C; a++) Q[i][a] = row[a * 256];
+                }
+            } else {
+                const float v[4] = {(float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
+                                    (float)(cur >> 24)};
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int a = 0; a <= C; a++) Q[i][a] = __fmul_rn(v[i], T[a]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float s = 0.0f;
@@ -468,12 +483,20 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 
 // Live state per lane: 4(2C+1) open sums + 4(C+1) products + ~30; without an occupancy target the scheduler
 // interleaves several rows' products and doubles that.
-template <int C>
+template <int C, bool USE_LUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 5 ? 5 : 4)))
 void gauss_sym_kernel(const uint8_t *__restrict__ img, int16_t *__restrict__ out, int H, int W, int n_strips,
                       int n_segs, int seg_rows, int total_waves, GaussTaps t, int use_fma_div, float fma_c)
 {
     using K = MarchCfg<C>;
+    // product table of the row pass (USE_LUT): the only LDS use and the only workgroup barrier of the kernel
+    __shared__ float lut_mem[USE_LUT ? (C + 1) * 256 : 1];
+    if (USE_LUT) {
+#pragma unroll
+        for (int a = 0; a <= C; a++) lut_mem[a * 256 + threadIdx.x] = __fmul_rn((float)threadIdx.x, t.tap[C - a]);
+        __syncthreads();
+    }
+    const float *lut = lut_mem;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
     if (wave >= total_waves) return;
@@ -497,16 +520,16 @@ void gauss_sym_kernel(const uint8_t *__restrict__ img, int16_t *__restrict__ out
     const bool row_edge = (jb.ybeg - C < 0) || (jb.yend + C + K::RING >= H);
     if (col_edge) {
         if (row_edge)
-            gauss_sym_strip<C, true, true>(jb, t);
+            gauss_sym_strip<C, true, true, false, USE_LUT>(jb, t, lut);
         else
-            gauss_sym_strip<C, true, false>(jb, t);
+            gauss_sym_strip<C, true, false, false, USE_LUT>(jb, t, lut);
     } else {
         if (row_edge)
-            gauss_sym_strip<C, false, true>(jb, t);
+            gauss_sym_strip<C, false, true, false, USE_LUT>(jb, t, lut);
         else if (use_fma_div)
-            gauss_sym_strip<C, false, false, true>(jb, t, fma_c);
+            gauss_sym_strip<C, false, false, true, USE_LUT>(jb, t, lut, fma_c);
         else
-            gauss_sym_strip<C, false, false>(jb, t);
+            gauss_sym_strip<C, false, false, false, USE_LUT>(jb, t, lut);
     }
 }
 
@@ -584,7 +607,9 @@ int gaussian_fma_div_table(const unsigned (**table)[2])
 
 static bool fma_div_enabled = true; // A/B switch (canny_hip_ctx_set_option "gaussian_fma_div")
 void gaussian_set_fma_div(bool on) { fma_div_enabled = on; }
-static int march_variant = 0; // A/B switch "tune_gaussian_variant": 0 = symmetric-tap kernel, 1 = LDS ring kernel
+// A/B switch "tune_gaussian_variant": 0 = symmetric-tap kernel with the row-pass products looked up in an LDS
+// table (default), 1 = LDS ring kernel, 2 = symmetric-tap kernel that multiplies
+static int march_variant = 0;
 void gaussian_set_march_variant(int v) { march_variant = v; }
 static int tune_seg_target = 0; // A/B switch "tune_gaussian_seg": approximate rows per wave segment, 0 = automatic
 void gaussian_set_seg_target(int rows) { tune_seg_target = rows; }
@@ -629,7 +654,7 @@ static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, i
     using K = MarchCfg<C>;
     int n_strips = (width + K::SW - 1) / K::SW;
     // the symmetric-tap kernel needs tap[C-a] == tap[C+a] bit for bit (true for the reference's taps)
-    bool symmetric = march_variant == 0;
+    bool symmetric = march_variant != 1;
     for (int a = 1; a <= C && symmetric; a++)
         symmetric = std::memcmp(&taps.tap[C - a], &taps.tap[C + a], sizeof(float)) == 0;
     // longest segments that still give the chip a few thousand waves; the symmetric kernel processes
@@ -660,9 +685,12 @@ static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, i
             use_fma = 1;
             std::memcpy(&fma_c, &e[1], sizeof(fma_c));
         }
-    if (symmetric)
-        hipLaunchKernelGGL(gauss_sym_kernel<C>, dim3(blocks), dim3(256), 0, stream, img, out, height, width, n_strips,
-                           n_segs, seg, (int)waves, taps, use_fma, fma_c);
+    if (symmetric && march_variant == 0)
+        hipLaunchKernelGGL((gauss_sym_kernel<C, true>), dim3(blocks), dim3(256), 0, stream, img, out, height, width,
+                           n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
+    else if (symmetric)
+        hipLaunchKernelGGL((gauss_sym_kernel<C, false>), dim3(blocks), dim3(256), 0, stream, img, out, height, width,
+                           n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
     else
         hipLaunchKernelGGL(gauss_march_kernel<C>, dim3(blocks), dim3(K::WPB * 64), 0, stream, img, out, height, width,
                            n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);

@@ -53,7 +53,8 @@ hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, i
 // process-wide (A/B measurements only).
 int gaussian_fma_div_table(const unsigned (**table)[2]);
 void gaussian_set_fma_div(bool on);
-// A/B: 0 = symmetric-tap kernel (shared products, register accumulators; default), 1 = LDS-ring kernel.
+// A/B: 0 = symmetric-tap kernel (shared products, register accumulators) with the row-pass products looked up
+// in an LDS table (default), 1 = LDS-ring kernel, 2 = symmetric-tap kernel that multiplies.
 void gaussian_set_march_variant(int v);
 void gaussian_set_seg_target(int rows); // A/B: approximate rows per wave segment, 0 = automatic
 

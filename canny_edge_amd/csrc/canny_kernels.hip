@@ -851,6 +851,7 @@ __global__ __launch_bounds__(256) void hyst_finalize_rows_kernel(int16_t *__rest
         v.y = __umul24((t >> 2) & 0x00010001u, ev);
         v.z = __umul24((t >> 4) & 0x00010001u, ev);
         v.w = __umul24((t >> 6) & 0x00010001u, ev);
+        // (non-temporal stores measured the same 0.218 ms)
         __builtin_memcpy(cand + ((size_t)f * g.height + y) * g.width + x0, &v, 16);
     }
 }
@@ -862,7 +863,7 @@ hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const Hys
                                 hipStream_t stream)
 {
     size_t total = (size_t)g.n_frames * g.height * g.width;
-    if (g.width % 8 == 0 && finalize_mode == 0) {
+    if (g.width % 8 == 0 && finalize_mode != 1) {
         const int groups = g.width / 8;
         hipLaunchKernelGGL(hyst_finalize_rows_kernel, dim3((groups + 255) / 256, (g.height + 3) / 4, g.n_frames),
                            dim3(256), 0, stream, cand, (const uint8_t *)strong, g, edge_value, groups);

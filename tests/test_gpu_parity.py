@@ -384,14 +384,15 @@ def test_invalid_arguments_are_rejected(ctx, hip):
 PATH_SHAPES = [(2, 2), (3, 70), (70, 3), (33, 250), (64, 496), (65, 497), (97, 505), (130, 1000), (300, 1240)]
 
 
-# path 1 = generic two-pass, 2 = marching (symmetric-tap kernel), 3 = marching (LDS-ring kernel);
+# path 1 = generic two-pass, 2 = marching (symmetric-tap kernel with the row-pass product table in LDS, the
+# default), 3 = marching (LDS-ring kernel), 4 = marching (symmetric-tap kernel that multiplies);
 # the sigmas give half-windows 1..8, i.e. every instantiation of the marching kernels
-@pytest.mark.parametrize("path", [1, 2, 3])
+@pytest.mark.parametrize("path", [1, 2, 3, 4])
 @pytest.mark.parametrize("sigma", [0.3, 0.5, 1.0, 1.2, 1.4, 2.0, 2.3, 2.6])
 def test_gaussian_paths(hip, path, sigma):
     with hip.Context(0) as c:
         c.set_option("gaussian_path", min(path, 2))
-        c.set_option("tune_gaussian_variant", 1 if path == 3 else 0)
+        c.set_option("tune_gaussian_variant", {3: 1, 4: 2}.get(path, 0))
         try:
             for shape in PATH_SHAPES + [(1, 1), (1, 300), (300, 1), (700, 260), (301, 2000)]:
                 for seed, gen in ((1, _noise), (2, _mixed)):

@@ -61,7 +61,7 @@ def main():
         print(f"  {name:14s} median {med:.4f} ms  min {mn:.4f} ms   {alg / med / 1e6:.0f} GB/s  ({alg / med / 8e9 * 100:.1f}% of 8 TB/s)")
     ctx.set_option("tune_sobel_seg", 0)
 
-    gmodes = [(variant, fma) for variant in (0, 1) for fma in (0, 1)]
+    gmodes = [(variant, fma) for variant in (0, 2, 1) for fma in (0, 1)]
     gres = {m: [] for m in gmodes}
     for _ in range(args.rounds):
         for variant, fma in gmodes:
@@ -73,8 +73,26 @@ def main():
     ctx.set_option("tune_gaussian_variant", 0)
     for variant, fma in gmodes:
         g = gres[(variant, fma)]
-        name = ("symmetric-tap" if variant == 0 else "LDS ring") + (", fma division" if fma else ", 5-op division")
+        name = {2: "symmetric-tap", 1: "LDS ring", 0: "symmetric-tap + product table"}[variant] + \
+            (", fma division" if fma else ", 5-op division")
         print(f"gaussian march [{name}]  median {statistics.median(g):.4f} ms  min {min(g):.4f} ms")
+    # worst case for the product table's LDS bank conflicts: uniformly random pixels
+    rng = np.random.default_rng(7)
+    noise = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    d_noise = ctx.malloc(F * H * W)
+    for i in range(F):
+        ctx.h2d(d_noise + i * H * W, np.roll(noise, 977 * i))
+    nres = {0: [], 2: []}
+    for _ in range(args.rounds):
+        for variant in (0, 2):
+            ctx.set_option("tune_gaussian_variant", variant)
+            nres[variant].append(time_stage(lambda: ctx.dev_gaussian(d_noise, args.sigma, H, W, F, d_sm),
+                                            capi.STAGE_GAUSSIAN))
+    ctx.set_option("tune_gaussian_variant", 0)
+    ctx.free(d_noise)
+    for variant in (0, 2):
+        print(f"gaussian on uniform noise, variant {variant}: median {statistics.median(nres[variant]):.4f} ms  "
+              f"min {min(nres[variant]):.4f} ms")
     segs = (0, 64, 100, 188, 265, 441)
     sres = {s: [] for s in segs}
     for _ in range(args.rounds):

@@ -185,11 +185,12 @@ def main():
     fused = stages["hyst_classify"]["launch_groups"] == 0  # canny() ran Sobel+NMS with the classify step inside
     sn_ms, sn_n = stages["sobel_nms"]["ms_per_step"], stages["sobel_nms"]["launch_groups"]
     if fused:
-        # The pass the pipeline actually runs: s16 smoothed in (2 B/px), two 1-bit planes out (2/8 B/px).  It
-        # is bound by VALU issue, not by HBM (DESIGN.md "Kernels"): ~25 VALU instructions per pixel.
+        # The pass the pipeline actually runs: s16 smoothed in (2 B/px); out: the provisional s16 edge map
+        # (2 B/px, completed in place by the propagation sweeps -- there is no finalize pass) and the two 1-bit
+        # hysteresis planes (2/8 B/px).  ~26 VALU instructions per pixel: VALU issue is the co-limiter.
         roofline = roof("sobel_nms_classify",
-                        "fused Sobel+NMS+threshold-classify (s16 smoothed in, strong/connectable bit-planes out)",
-                        2.25, sn_ms, sn_n, {"limiter": "VALU issue (see DESIGN.md); HBM traffic was cut instead"})
+                        "fused Sobel+NMS+threshold-classify (s16 smoothed in; s16 edge map + strong/connectable "
+                        "bit-planes out)", 4.25, sn_ms, sn_n, {"limiter": "VALU issue and HBM, see DESIGN.md"})
     else:
         roofline = roof("sobel_nms", "fused Sobel+NMS (s16 smoothed in, s16 suppressed magnitude out)", 4.0,
                         sn_ms, sn_n)
@@ -216,9 +217,11 @@ def main():
         "gaussian": roof("gaussian", "separable Gaussian, rows+columns in one kernel (u8 in, s16 out)", 3.0,
                          stages["gaussian"]["ms_per_step"], stages["gaussian"]["launch_groups"],
                          {"limiter": "VALU issue: separately rounded f32 mul/add chains (bit-exactness)"}),
-        "hyst_finalize": roof("hyst_finalize", "hysteresis finalize (1-bit plane in, s16 edge map out)", 2.125,
-                              stages["hyst_finalize"]["ms_per_step"], stages["hyst_finalize"]["launch_groups"]),
     }
+    if stages["hyst_finalize"]["launch_groups"]:
+        per_kernel["hyst_finalize"] = roof("hyst_finalize", "hysteresis finalize (1-bit plane in, s16 edge map out)",
+                                           2.125, stages["hyst_finalize"]["ms_per_step"],
+                                           stages["hyst_finalize"]["launch_groups"])
     if not fused:
         per_kernel["hyst_classify"] = roof("hyst_classify", "hysteresis classify (s16 in, two 1-bit planes out)", 2.25,
                                            stages["hyst_classify"]["ms_per_step"],

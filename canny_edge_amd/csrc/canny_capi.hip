@@ -223,8 +223,11 @@ int prepare_hyst(canny_hip_ctx *ctx, const HystGeom &g, bool zero_pad)
 // finalize kernel), so it is launched right behind each chunk of sweeps, BEFORE the host has seen the flag;
 // the host waits on an event recorded behind the flag copy only, and the GPU never idles for the round trip.
 // If the flag says "not converged" (rare) the consumer simply runs again behind the next chunk.
+// edges != nullptr: the sweeps write the pixels they promote straight into that edge map (which must already
+// hold the strong pixels); there is then nothing left for a consumer to do.
 template <class Consumer>
-int run_propagation(canny_hip_ctx *ctx, const HystGeom &g, bool speculative, Consumer &&consumer)
+int run_propagation(canny_hip_ctx *ctx, const HystGeom &g, bool speculative, Consumer &&consumer,
+                    short *edges = nullptr, int edge_value = 0)
 {
     uint64_t *S = (uint64_t *)ctx->plane_s.p;
     const uint64_t *C = (const uint64_t *)ctx->plane_c.p;
@@ -237,7 +240,7 @@ int run_propagation(canny_hip_ctx *ctx, const HystGeom &g, bool speculative, Con
         {
             StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_PROPAGATE);
             for (int k = 0; k < chunk; k++)
-                HIP_TRY(ctx, launch_hyst_propagate(S, C, stamp, flags, iter + k, g, ctx->stream));
+                HIP_TRY(ctx, launch_hyst_propagate(S, C, stamp, flags, iter + k, g, ctx->stream, edges, edge_value));
         }
         iter += chunk;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->host_flags, flags, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
@@ -305,11 +308,15 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
         if ((rc = ensure_hyst(ctx, g))) return rc;
         uint64_t *S = (uint64_t *)ctx->plane_s.p, *C = (uint64_t *)ctx->plane_c.p;
         if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc; // the kernel below writes in-image bytes only
+        // reached pixels hold EDGE=255 and survive the reference's final `< max_val -> 0` sweep only if 255 >= max_val
+        const int edge_value = 255 >= hi ? 255 : 0;
         {
             StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
-            HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, S, C, g, lo, hi, ctx->stream, ctx->tune_sobel_seg));
+            HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, S, C, g, lo, hi, edge_value, ctx->stream,
+                                                         ctx->tune_sobel_seg));
         }
-        return propagate_and_finalize(ctx, g, d_edges, hi);
+        // d_edges now holds the strong pixels; the sweeps add every pixel they promote: no finalize pass
+        return run_propagation(ctx, g, /*speculative=*/false, []() -> int { return CANNY_HIP_OK; }, d_edges, edge_value);
     }
     if ((rc = dev_sobel_nms(ctx, sm, h, w, n, d_edges))) return rc;
     return dev_hysteresis(ctx, d_edges, h, w, n, lo, hi);

@@ -76,10 +76,13 @@ hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int hei
 
 // Fused Sobel+NMS+classify: the same marching kernel, but instead of the s16 suppressed magnitudes it
 // writes the two hysteresis bit-planes that launch_hyst_classify would derive from them (in-image bytes
-// only: pair it with launch_hyst_prepare(..., zero_pad = true)).  Needs width % 8 == 0 and min_val >= 1.
+// only: pair it with launch_hyst_prepare(..., zero_pad = true)) and the provisional edge map `edges`
+// (strong pixels -> edge_value, everything else 0) that launch_hyst_propagate(..., edges, edge_value) completes.
+// Needs width % 8 == 0 and min_val >= 1.
 bool sobel_nms_classify_supported(int height, int width, int min_val);
-hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, uint64_t *strong, uint64_t *conn, const HystGeom &g,
-                                           int min_val, int max_val, hipStream_t stream, int tune_seg = 0);
+hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, int16_t *edges, uint64_t *strong, uint64_t *conn,
+                                           const HystGeom &g, int min_val, int max_val, int edge_value,
+                                           hipStream_t stream, int tune_seg = 0);
 
 // ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
 hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,
@@ -92,8 +95,11 @@ inline size_t hyst_sched_words(const HystGeom &g) { return 3 * (size_t)g.tiles()
 // by launch_sobel_nms_classify_march, which writes in-image bytes only; requires width % 8 == 0).
 hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom &g, bool zero_pad, unsigned *sched,
                                unsigned *flags, hipStream_t stream);
+// edges != nullptr: an edge map that already holds the initially strong pixels; each sweep writes edge_value
+// into the pixels it promotes, so the map is final when propagation has converged (no finalize pass).
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
-                                 int iter, const HystGeom &g, hipStream_t stream);
+                                 int iter, const HystGeom &g, hipStream_t stream, int16_t *edges = nullptr,
+                                 int edge_value = 0);
 hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const HystGeom &g, int edge_value,
                                 hipStream_t stream);
 void hyst_set_finalize_mode(int mode); // A/B: 0 = row-major kernel (default), 1 = 8-row patch kernel

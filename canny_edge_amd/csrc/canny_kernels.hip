@@ -431,9 +431,12 @@ __device__ __forceinline__ HystSched make_sched(unsigned *words, int tiles)
     return s;
 }
 
+// edges (may be null): edge map that already holds the initially strong pixels (written by the kernel that
+// filled the planes); every pixel this sweep promotes is written there at once, so no finalize pass is needed.
 __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__restrict__ strong,
                                                const uint64_t *__restrict__ conn, const HystSched &sch,
-                                               unsigned *__restrict__ last_change, int iter, const HystGeom &g)
+                                               unsigned *__restrict__ last_change, int iter, const HystGeom &g,
+                                               int16_t *__restrict__ edges, int edge_value)
 {
     const int tpf = g.tiles_x * g.tiles_y;
     const int tt = t % tpf;
@@ -498,6 +501,17 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
     const uint64_t chg = s ^ s0;
     if (__any(chg != 0)) {
         strong[base + lane] = s;
+        if (edges && ty * kTile + lane < g.height) { // a handful of pixels per row at most: plain 2-byte stores
+            const int f = t / tpf;
+            int16_t *rowp = edges + ((size_t)f * g.height + (size_t)(ty * kTile + lane)) * g.width + tx * kTile;
+            // (padding bits are never connectable, so every set bit lies inside the image; the column test only
+            // keeps a corrupted plane from turning into an out-of-bounds store)
+            const int cols = min(kTile, g.width - tx * kTile);
+            for (uint64_t m = chg; m != 0; m &= m - 1) {
+                const int b = __builtin_ctzll(m);
+                if (b < cols) rowp[b] = (int16_t)edge_value;
+            }
+        }
         const uint64_t top64 = lane_u64(chg, 0);  // changes in the tile's first row
         const uint64_t bot = lane_u64(chg, 63);   // ... and in its last row
         const bool anyL = __any((chg & 1ull) != 0), anyR = __any((chg >> 63) != 0);
@@ -530,7 +544,8 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
 __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restrict__ strong,
                                                              const uint64_t *__restrict__ conn,
                                                              unsigned *__restrict__ sched_words,
-                                                             unsigned *__restrict__ last_change, int iter, HystGeom g)
+                                                             unsigned *__restrict__ last_change, int iter, HystGeom g,
+                                                             int16_t *__restrict__ edges, int edge_value)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -539,13 +554,14 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
     const HystSched sch = make_sched(sched_words, tiles);
     if (wave == 0 && lane == 0) sch.count[(iter + 2) % 3] = 0; // the slot sweep iter+1 will append to
     if (iter == 0) {
-        for (int t = wave; t < tiles; t += n_waves) propagate_tile(t, lane, strong, conn, sch, last_change, iter, g);
+        for (int t = wave; t < tiles; t += n_waves)
+            propagate_tile(t, lane, strong, conn, sch, last_change, iter, g, edges, edge_value);
         return;
     }
     const unsigned n = __hip_atomic_load(sch.count + iter % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned *q = (iter & 1) ? sch.queue1 : sch.queue0;
     for (unsigned i = (unsigned)wave; i < n; i += (unsigned)n_waves)
-        propagate_tile((int)q[i], lane, strong, conn, sch, last_change, iter, g);
+        propagate_tile((int)q[i], lane, strong, conn, sch, last_change, iter, g, edges, edge_value);
 }
 
 __global__ __launch_bounds__(256) void hyst_finalize_kernel(int16_t *__restrict__ cand,
@@ -811,12 +827,12 @@ hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom 
 }
 
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *stamp, unsigned *last_change,
-                                 int iter, const HystGeom &g, hipStream_t stream)
+                                 int iter, const HystGeom &g, hipStream_t stream, int16_t *edges, int edge_value)
 {
     unsigned blocks = (unsigned)((g.tiles() + 3) / 4);
     if (iter > 0 && blocks > 1024u) blocks = 1024u; // queue walkers: 16 waves per CU
     hipLaunchKernelGGL(hyst_propagate_kernel, dim3(blocks), dim3(256), 0, stream, strong, conn, stamp, last_change,
-                       iter, g);
+                       iter, g, edges, edge_value);
     return hipGetLastError();
 }
 // Row-major finalize: a wave writes 512 consecutive pixels of ONE row (1 KB contiguous, four rows per

@@ -94,6 +94,7 @@ struct StripJob {
     // PLANES only: this frame's hysteresis bit-planes (tile-major, see HystGeom) and the thresholds
     uint8_t *pconn, *pstrong;
     int tiles_x, lo1, hi1; // lo1 = min_val - 1, hi1 = max(min_val, max_val) - 1
+    int edge_value;        // what a strong pixel becomes in the edge map (EDGE, or 0 if max_val > EDGE)
 };
 
 // COL_EDGE: the strip touches column 0 or W-1 (lane-varying masks, partial lanes).
@@ -104,8 +105,10 @@ struct StripJob {
 // them (src/utils.cpp:331-351): bit-plane `connectable` (v >= min_val) and `strong` (v >= min_val and
 // v >= max_val), one byte per lane and row.  Requires min_val >= 1 (then v >= min_val implies the pixel
 // survived NMS, so the threshold folds into the NMS comparison: mc > max(neighbour, min_val - 1)) and
-// W % 8 == 0 (a lane's 8 pixels are one plane byte).  The s16 plane is never written: 2 B/px of stores and
-// the whole classify pass (2 B/px of loads) disappear from the pipeline.
+// W % 8 == 0 (a lane's 8 pixels are one plane byte).  The s16 plane it writes is not the suppressed magnitude
+// but the provisional EDGE MAP (strong -> edge value, else 0), which the propagation sweeps complete in place:
+// the classify pass (2 B/px of loads) and the finalize pass (2 B/px of stores in an HBM-bound kernel) both
+// disappear from the pipeline, and this kernel's own stores hide behind its VALU work.
 template <bool COL_EDGE, bool ROW_EDGE, bool PLANES>
 __device__ __forceinline__ void march_strip(const StripJob &jb)
 {
@@ -280,8 +283,19 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
                     const unsigned bx = (unsigned)x0 >> 3;
                     const unsigned off = ((unsigned)(y2 >> 6) * (unsigned)jb.tiles_x + (bx >> 3)) * 512u +
                                          (unsigned)(y2 & 63) * 8u + (bx & 7u);
+                    const unsigned sb = sbits & cbits;
                     jb.pconn[off] = (uint8_t)cbits;
-                    jb.pstrong[off] = (uint8_t)(sbits & cbits);
+                    jb.pstrong[off] = (uint8_t)sb;
+                    // Provisional edge map: strong pixels already carry their final value, everything else 0;
+                    // the propagation sweeps add the weak pixels they promote.  These 2 B/px ride along for
+                    // free (the kernel is VALU bound) and replace the separate finalize pass.
+                    const uint32_t tb = sb | (sb << 15); // bit 2k -> bit 0, bit 2k+1 -> bit 16 of pair k
+                    uint4 v;
+                    v.x = __umul24(tb & 0x00010001u, (uint32_t)jb.edge_value);
+                    v.y = __umul24((tb >> 2) & 0x00010001u, (uint32_t)jb.edge_value);
+                    v.z = __umul24((tb >> 4) & 0x00010001u, (uint32_t)jb.edge_value);
+                    v.w = __umul24((tb >> 6) & 0x00010001u, (uint32_t)jb.edge_value);
+                    __builtin_memcpy(jb.fout + (size_t)y2 * W + x0, &v, 16);
                 }
             } else if (owner) {
                 int16_t *dst = jb.fout + (size_t)y2 * W + x0;
@@ -319,7 +333,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
 
 struct PlaneArgs { // PLANES instantiation only
     uint8_t *conn, *strong;
-    int tiles_x, tiles_y, lo1, hi1;
+    int tiles_x, tiles_y, lo1, hi1, edge_value;
 };
 
 template <bool PLANES>
@@ -343,8 +357,9 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
     jb.yend = min(H, jb.ybeg + seg_rows);
     jb.x0 = s * SNM_SW + (jb.lane - 1) * SNM_PX; // column of this lane's pixel 0
     jb.fin = in + (size_t)f * H * W;
-    jb.fout = PLANES ? nullptr : out + (size_t)f * H * W;
+    jb.fout = out + (size_t)f * H * W; // PLANES: the provisional edge map
     if (PLANES) {
+        jb.edge_value = pl.edge_value;
         const size_t frame_bytes = (size_t)pl.tiles_y * pl.tiles_x * 512;
         jb.pconn = pl.conn + (size_t)f * frame_bytes;
         jb.pstrong = pl.strong + (size_t)f * frame_bytes;
@@ -385,8 +400,8 @@ static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const Plan
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;
     unsigned blocks = (unsigned)((waves + SNM_WPB - 1) / SNM_WPB);
     if (planes)
-        hipLaunchKernelGGL(sobel_nms_march_kernel<true>, dim3(blocks), dim3(SNM_WPB * 64), 0, stream, smoothed,
-                           (int16_t *)nullptr, height, width, n_strips, n_segs, seg, (int)waves, *planes);
+        hipLaunchKernelGGL(sobel_nms_march_kernel<true>, dim3(blocks), dim3(SNM_WPB * 64), 0, stream, smoothed, out,
+                           height, width, n_strips, n_segs, seg, (int)waves, *planes);
     else
         hipLaunchKernelGGL(sobel_nms_march_kernel<false>, dim3(blocks), dim3(SNM_WPB * 64), 0, stream, smoothed, out,
                            height, width, n_strips, n_segs, seg, (int)waves, PlaneArgs{});
@@ -405,10 +420,12 @@ bool sobel_nms_classify_supported(int height, int width, int min_val)
     return sobel_nms_march_supported(height, width) && width % 8 == 0 && min_val >= 1;
 }
 
-hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, uint64_t *strong, uint64_t *conn, const HystGeom &g,
-                                           int min_val, int max_val, hipStream_t stream, int tune_seg)
+hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, int16_t *edges, uint64_t *strong, uint64_t *conn,
+                                           const HystGeom &g, int min_val, int max_val, int edge_value,
+                                           hipStream_t stream, int tune_seg)
 {
     if (!sobel_nms_classify_supported(g.height, g.width, min_val)) return hipErrorNotSupported;
+    if (edge_value < 0 || edge_value > 32767) return hipErrorInvalidValue;
     // magnitudes are <= 1442, so thresholds beyond that all mean "never"; clamping keeps hi1 from overflowing
     const int lo = min_val > 4096 ? 4096 : min_val;
     const int hi = max_val > 4096 ? 4096 : max_val;
@@ -419,7 +436,8 @@ hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, uint64_t *st
     pl.tiles_y = g.tiles_y;
     pl.lo1 = lo - 1;
     pl.hi1 = (hi > lo ? hi : lo) - 1;
-    return launch_march(smoothed, nullptr, &pl, g.height, g.width, g.n_frames, stream, tune_seg);
+    pl.edge_value = edge_value;
+    return launch_march(smoothed, edges, &pl, g.height, g.width, g.n_frames, stream, tune_seg);
 }
 
 } // namespace canny

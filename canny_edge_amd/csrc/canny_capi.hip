@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -77,8 +78,10 @@ struct canny_hip_ctx {
     DevBuf smoothed;  // pipeline: Gaussian output
     DevBuf plane_s, plane_c, stamps, flags; // hysteresis bit-planes / scheduling words
     DevBuf io[4];     // staging for the host-pointer stage functions
-    unsigned *host_flags = nullptr; // pinned, 2 words
-    hipEvent_t flag_event = nullptr; // recorded behind the copy of the flags to host_flags
+    unsigned *host_flags = nullptr;     // pinned + mapped, 4 words: last_change, domain, sequence number, spare
+    unsigned *host_flags_dev = nullptr; // the same memory as the device sees it
+    unsigned publish_seq = 0;           // sequence number of the last launch_hyst_publish
+    hipEvent_t flag_event = nullptr;    // recorded behind the publish kernel (fallback wait)
 
     // profiling
     bool prof = false;
@@ -202,7 +205,11 @@ int ensure_hyst(canny_hip_ctx *ctx, const HystGeom &g)
     HIP_TRY(ctx, ctx->plane_c.ensure(g.words() * sizeof(uint64_t)));
     HIP_TRY(ctx, ctx->stamps.ensure(hyst_sched_words(g) * sizeof(unsigned)));
     HIP_TRY(ctx, ctx->flags.ensure(2 * sizeof(unsigned)));
-    if (!ctx->host_flags) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->host_flags, 2 * sizeof(unsigned)));
+    if (!ctx->host_flags) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->host_flags, 4 * sizeof(unsigned), hipHostMallocMapped));
+        std::memset(ctx->host_flags, 0, 4 * sizeof(unsigned));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->host_flags_dev, ctx->host_flags, 0));
+    }
     if (!ctx->flag_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->flag_event, hipEventDisableTiming));
     return CANNY_HIP_OK;
 }
@@ -243,10 +250,25 @@ int run_propagation(canny_hip_ctx *ctx, const HystGeom &g, bool speculative, Con
                 HIP_TRY(ctx, launch_hyst_propagate(S, C, stamp, flags, iter + k, g, ctx->stream, edges, edge_value));
         }
         iter += chunk;
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->host_flags, flags, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->flag_event, ctx->stream));
+        // A one-thread kernel publishes the two flag words and a sequence number in pinned host memory and the
+        // host spins on the sequence number: ~5 us from the last sweep to the host knowing, against ~35 us for
+        // an async copy plus an event wait (copy-engine hand-over, interrupt, wake-up).
+        const unsigned seq = ++ctx->publish_seq;
+        HIP_TRY(ctx, launch_hyst_publish(flags, ctx->host_flags_dev, seq, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->flag_event, ctx->stream)); // fallback if the spin times out
         if (speculative && (rc = consumer())) return rc;
-        HIP_TRY(ctx, hipEventSynchronize(ctx->flag_event));
+        {
+            volatile unsigned *hf = ctx->host_flags;
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (__atomic_load_n(&hf[2], __ATOMIC_ACQUIRE) != seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                    HIP_TRY(ctx, hipEventSynchronize(ctx->flag_event)); // errors surface here
+                    if (__atomic_load_n(&hf[2], __ATOMIC_ACQUIRE) != seq) return CANNY_HIP_ERR_RUNTIME;
+                }
+            }
+        }
         if (ctx->host_flags[1]) return CANNY_HIP_ERR_DOMAIN;
         if (ctx->host_flags[0] != (unsigned)iter) break; // nothing scheduled for sweep `iter`
         if (iter >= kMaxSweeps) return CANNY_HIP_ERR_NO_CONVERGE;

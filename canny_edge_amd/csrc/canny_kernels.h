@@ -100,6 +100,9 @@ hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom 
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
                                  int iter, const HystGeom &g, hipStream_t stream, int16_t *edges = nullptr,
                                  int edge_value = 0);
+// Copies flags[0..1] (last_change, domain) to host_flags_dev[0..1] and then stores seq to host_flags_dev[2]
+// (system-scope release); host_flags_dev is the device view of pinned, mapped host memory.
+hipError_t launch_hyst_publish(const unsigned *flags, unsigned *host_flags_dev, unsigned seq, hipStream_t stream);
 hipError_t launch_hyst_finalize(int16_t *cand, const uint64_t *strong, const HystGeom &g, int edge_value,
                                 hipStream_t stream);
 void hyst_set_finalize_mode(int mode); // A/B: 0 = row-major kernel (default), 1 = 8-row patch kernel

@@ -826,6 +826,20 @@ hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom 
     return hipGetLastError();
 }
 
+// Publishes flags[0..1] and a sequence number in host-visible (pinned, mapped) memory: the host polls host[2].
+__global__ void hyst_publish_kernel(const unsigned *__restrict__ flags, unsigned *host, unsigned seq)
+{
+    __hip_atomic_store(&host[0], flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host[1], flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&host[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_hyst_publish(const unsigned *flags, unsigned *host_flags_dev, unsigned seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hyst_publish_kernel, dim3(1), dim3(1), 0, stream, flags, host_flags_dev, seq);
+    return hipGetLastError();
+}
+
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *stamp, unsigned *last_change,
                                  int iter, const HystGeom &g, hipStream_t stream, int16_t *edges, int edge_value)
 {

@@ -421,6 +421,7 @@ __device__ __forceinline__ uint64_t row_below_u64(uint64_t v)
 struct HystSched {
     unsigned *stamp, *queue0, *queue1, *count;
 };
+constexpr int kSweep0Tiles = 4; // tiles per wave in sweep 0
 __device__ __forceinline__ HystSched make_sched(unsigned *words, int tiles)
 {
     HystSched s;
@@ -436,8 +437,12 @@ __device__ __forceinline__ HystSched make_sched(unsigned *words, int tiles)
 __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__restrict__ strong,
                                                const uint64_t *__restrict__ conn, const HystSched &sch,
                                                unsigned *__restrict__ last_change, int iter, const HystGeom &g,
-                                               int16_t *__restrict__ edges, int edge_value)
+                                               int16_t *__restrict__ edges, int edge_value, uint64_t c)
 {
+    // c = this lane's word of the tile's connectable plane, loaded by the caller.  Only connectable pixels can
+    // ever be added, so a tile without a single one (flat regions: most tiles of a natural frame) cannot
+    // change: leave before the strong plane and the nine halo loads are touched.
+    if (!__any(c != 0)) return;
     const int tpf = g.tiles_x * g.tiles_y;
     const int tt = t % tpf;
     const int ty = tt / g.tiles_x, tx = tt - ty * g.tiles_x;
@@ -445,10 +450,6 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
     const size_t base = (size_t)t * kTile;
     const size_t rowstep = (size_t)g.tiles_x * kTile; // words between vertically adjacent tiles
 
-    const uint64_t c = conn[base + lane];
-    // Only connectable pixels can ever be added, so a tile without a single one (flat regions: most tiles of a
-    // natural frame) cannot change: leave before the strong plane and the nine halo loads are touched.
-    if (!__any(c != 0)) return;
     const uint64_t s0 = strong[base + lane];
     // halo from the eight neighbouring tiles (read once per sweep; a change made there during
     // this sweep re-stamps us for the next one)
@@ -554,14 +555,27 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
     const HystSched sch = make_sched(sched_words, tiles);
     if (wave == 0 && lane == 0) sch.count[(iter + 2) % 3] = 0; // the slot sweep iter+1 will append to
     if (iter == 0) {
-        for (int t = wave; t < tiles; t += n_waves)
-            propagate_tile(t, lane, strong, conn, sch, last_change, iter, g, edges, edge_value);
+        // Four tiles per wave, their connectable words loaded up front: most tiles are empty and cost exactly
+        // this one load, so what matters is how many of them are in flight (a wave per tile was bound by the
+        // latency of 130 k single loads).
+        for (int t0 = wave * kSweep0Tiles; t0 < tiles; t0 += n_waves * kSweep0Tiles) {
+            uint64_t c[kSweep0Tiles];
+#pragma unroll
+            for (int k = 0; k < kSweep0Tiles; k++)
+                c[k] = (t0 + k < tiles) ? conn[(size_t)(t0 + k) * kTile + lane] : 0ull;
+#pragma unroll
+            for (int k = 0; k < kSweep0Tiles; k++)
+                propagate_tile(t0 + k, lane, strong, conn, sch, last_change, iter, g, edges, edge_value, c[k]);
+        }
         return;
     }
     const unsigned n = __hip_atomic_load(sch.count + iter % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned *q = (iter & 1) ? sch.queue1 : sch.queue0;
-    for (unsigned i = (unsigned)wave; i < n; i += (unsigned)n_waves)
-        propagate_tile((int)q[i], lane, strong, conn, sch, last_change, iter, g, edges, edge_value);
+    for (unsigned i = (unsigned)wave; i < n; i += (unsigned)n_waves) {
+        const int t = (int)q[i];
+        propagate_tile(t, lane, strong, conn, sch, last_change, iter, g, edges, edge_value,
+                       conn[(size_t)t * kTile + lane]);
+    }
 }
 
 __global__ __launch_bounds__(256) void hyst_finalize_kernel(int16_t *__restrict__ cand,
@@ -843,7 +857,7 @@ hipError_t launch_hyst_publish(const unsigned *flags, unsigned *host_flags_dev, 
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *stamp, unsigned *last_change,
                                  int iter, const HystGeom &g, hipStream_t stream, int16_t *edges, int edge_value)
 {
-    unsigned blocks = (unsigned)((g.tiles() + 3) / 4);
+    unsigned blocks = (unsigned)((g.tiles() + 4 * kSweep0Tiles - 1) / (4 * kSweep0Tiles)); // sweep 0: all tiles
     if (iter > 0 && blocks > 1024u) blocks = 1024u; // queue walkers: 16 waves per CU
     hipLaunchKernelGGL(hyst_propagate_kernel, dim3(blocks), dim3(256), 0, stream, strong, conn, stamp, last_change,
                        iter, g, edges, edge_value);

@@ -71,6 +71,7 @@ hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, i
                             bool domain8, hipStream_t stream);
 // Fused Sobel+NMS, wave-marching and LDS-free (canny_sobel_nms_march.hip); smoothed must lie in [0,255].
 bool sobel_nms_march_supported(int height, int width);
+void sobel_nms_set_px_variant(int v); // A/B: 0 = 8 pixels per lane, 1 = 4 pixels per lane (more resident waves)
 hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
                                   hipStream_t stream, int tune_prefetch = 0, int tune_seg = 0);
 

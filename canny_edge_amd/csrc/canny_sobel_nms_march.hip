@@ -80,8 +80,13 @@ __device__ __forceinline__ void push_gt(unsigned &bits, int a, int b)
     asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
 }
 
-constexpr int SNM_PX = 8;           // pixels per lane
-constexpr int SNM_SW = 62 * SNM_PX; // output columns per strip
+// NP = packed s16 pairs per lane: 4 (8 pixels, 16-byte accesses, ~146 VGPRs: 3 waves per SIMD) or 2 (4 pixels,
+// 8-byte accesses, fewer registers: more resident waves to hide the store and load latency behind).
+template <int NP>
+struct SnmCfg {
+    static constexpr int PX = 2 * NP;  // pixels per lane
+    static constexpr int SW = 62 * PX; // output columns per strip (lanes 0 and 63 are halo lanes)
+};
 constexpr int SNM_WPB = 4;          // waves per workgroup (independent of each other)
 
 template <int N>
@@ -109,46 +114,40 @@ struct StripJob {
 // but the provisional EDGE MAP (strong -> edge value, else 0), which the propagation sweeps complete in place:
 // the classify pass (2 B/px of loads) and the finalize pass (2 B/px of stores in an HBM-bound kernel) both
 // disappear from the pipeline, and this kernel's own stores hide behind its VALU work.
-template <bool COL_EDGE, bool ROW_EDGE, bool PLANES>
+template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP>
 __device__ __forceinline__ void march_strip(const StripJob &jb)
 {
+    constexpr int PX = 2 * NP;
     const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend;
-    const bool full8 = x0 >= 0 && x0 + 7 < W;
+    const bool full8 = x0 >= 0 && x0 + PX - 1 < W; // all of this lane's pixels are inside the image
     const bool owner = jb.lane >= 1 && jb.lane <= 62 && x0 < W;
 
     // lane-varying border masks (COL_EDGE only)
-    uint32_t fix_l = 0, fix_r[4] = {0, 0, 0, 0};
+    uint32_t fix_l = 0, fix_r[NP] = {};
     unsigned oob = 0; // bit e set: column x0+e is outside the image
     if (COL_EDGE) {
         fix_l = (x0 == 0) ? 0x0000ffffu : 0u; // column 0 = low half of pair 0
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NP; i++) {
             if (x0 + 2 * i == W - 1) fix_r[i] |= 0x0000ffffu;
             if (x0 + 2 * i + 1 == W - 1) fix_r[i] |= 0xffff0000u;
         }
 #pragma unroll
-        for (int e = 0; e < 8; e++)
+        for (int e = 0; e < PX; e++)
             if (x0 + e < 0 || x0 + e >= W) oob |= 1u << e;
     }
 
-    auto load_row = [&](int r, uint32_t (&p)[4]) {
-        if (ROW_EDGE && (r < 0 || r >= H)) { // wave-uniform: virtual rows are zero
-            p[0] = p[1] = p[2] = p[3] = 0u;
-            return;
-        }
+    auto load_row = [&](int r, uint32_t (&p)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) p[i] = 0u;
+        if (ROW_EDGE && (r < 0 || r >= H)) return; // wave-uniform: virtual rows are zero
         const int16_t *src = jb.fin + (size_t)r * W + x0;
         if (!COL_EDGE || full8) {
-            uint4 v;
-            __builtin_memcpy(&v, src, 16);
-            p[0] = v.x;
-            p[1] = v.y;
-            p[2] = v.z;
-            p[3] = v.w;
+            __builtin_memcpy(p, src, 4 * NP); // one 16-byte (8-byte) load
         } else {
-            p[0] = p[1] = p[2] = p[3] = 0u;
-            if (x0 + 7 >= 0 && x0 < W) {
+            if (x0 + PX - 1 >= 0 && x0 < W) {
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
+                for (int e = 0; e < PX; e++) {
                     int x = x0 + e;
                     if (x >= 0 && x < W) p[e >> 1] |= (uint32_t)(uint16_t)src[e] << (16 * (e & 1));
                 }
@@ -157,63 +156,62 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
     };
 
     // rotating state (all indices are compile-time after unrolling by 3)
-    uint32_t d[3][4], t[3][4]; // horizontal difference / smooth of rows r, r-1, r-2
-    int M[3][10];              // magnitudes of rows r-1, r-2, r-3; [0] and [9] are the neighbours' edge pixels
-    float cP[3][8], cQ[3][8];  // bin discriminants (slot of the row they belong to)
+    uint32_t d[3][NP], t[3][NP]; // horizontal difference / smooth of rows r, r-1, r-2
+    int M[3][PX + 2];            // magnitudes of rows r-1, r-2, r-3; [0] and [PX+1] are the neighbours' edge pixels
+    float cP[3][PX], cQ[3][PX];  // bin discriminants (slot of the row they belong to)
 #pragma unroll
     for (int a = 0; a < 3; a++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) d[a][i] = t[a][i] = 0u;
+        for (int i = 0; i < NP; i++) d[a][i] = t[a][i] = 0u;
 #pragma unroll
-        for (int e = 0; e < 10; e++) M[a][e] = -1;
+        for (int e = 0; e < PX + 2; e++) M[a][e] = -1;
 #pragma unroll
-        for (int e = 0; e < 8; e++) cP[a][e] = cQ[a][e] = 0.0f;
+        for (int e = 0; e < PX; e++) cP[a][e] = cQ[a][e] = 0.0f;
     }
 
     // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
-    auto step = [&](auto ph, int r, const uint32_t (&p)[4]) {
+    auto step = [&](auto ph, int r, const uint32_t (&p)[NP]) {
         constexpr int PH = decltype(ph)::value;
         constexpr int k2 = PH % 3, k1 = (PH + 2) % 3, k0 = (PH + 1) % 3; // d/t of rows r, r-1, r-2
         constexpr int m2 = PH % 3, m1 = (PH + 2) % 3, m0 = (PH + 1) % 3; // M and bins of rows r-1, r-2, r-3
 
         // ---- horizontal step for row r ---------------------------------------------------------
         {
-            const uint32_t lp = from_left(p[3]), rp = from_right(p[0]);
-            uint32_t sh[5]; // sh[i] = (pixel 2i-1, pixel 2i)
+            const uint32_t lp = from_left(p[NP - 1]), rp = from_right(p[0]);
+            uint32_t sh[NP + 1]; // sh[i] = (pixel 2i-1, pixel 2i)
             sh[0] = __builtin_amdgcn_alignbit(p[0], lp, 16);
-            sh[1] = __builtin_amdgcn_alignbit(p[1], p[0], 16);
-            sh[2] = __builtin_amdgcn_alignbit(p[2], p[1], 16);
-            sh[3] = __builtin_amdgcn_alignbit(p[3], p[2], 16);
-            sh[4] = __builtin_amdgcn_alignbit(rp, p[3], 16);
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 1; i < NP; i++) sh[i] = __builtin_amdgcn_alignbit(p[i], p[i - 1], 16);
+            sh[NP] = __builtin_amdgcn_alignbit(rp, p[NP - 1], 16);
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
                 d[k2][i] = pk_sub(sh[i + 1], sh[i]);
                 t[k2][i] = pk_mad2(p[i], pk_add(sh[i], sh[i + 1]));
             }
             if (COL_EDGE) {
                 d[k2][0] = pk_sub(d[k2][0], p[0] & fix_l); // clamp at column 0
 #pragma unroll
-                for (int i = 0; i < 4; i++) d[k2][i] = pk_add(d[k2][i], p[i] & fix_r[i]); // ... and at column W-1
+                for (int i = 0; i < NP; i++) d[k2][i] = pk_add(d[k2][i], p[i] & fix_r[i]); // ... and at column W-1
             }
         }
 
         // ---- gradient, magnitude and bin discriminants for row y1 = r-1 ------------------------
         const int y1 = r - 1;
         if (!ROW_EDGE || (y1 >= 0 && y1 < H)) {
-            uint32_t gy[4];
+            uint32_t gy[NP];
             if (ROW_EDGE && (y1 == 0 || y1 == H - 1)) { // row clamp: t[-1] := t[0], t[H] := t[H-1]
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < NP; i++) {
                     const uint32_t tu = (y1 == 0) ? t[k1][i] : t[k0][i];
                     const uint32_t td = (y1 == H - 1) ? t[k1][i] : t[k2][i];
                     gy[i] = pk_sub(td, tu);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) gy[i] = pk_sub(t[k2][i], t[k0][i]);
+                for (int i = 0; i < NP; i++) gy[i] = pk_sub(t[k2][i], t[k0][i]);
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NP; i++) {
                 const uint32_t gx = pk_add(pk_mad2(d[k1][i], d[k0][i]), d[k2][i]);
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
@@ -231,26 +229,26 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
             }
             if (COL_EDGE) { // columns outside the image never win a comparison
 #pragma unroll
-                for (int e = 0; e < 8; e++)
+                for (int e = 0; e < PX; e++)
                     if (oob & (1u << e)) M[m2][e + 1] = -1;
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; e++) M[m2][e + 1] = -1; // rows outside the image are skipped by NMS
+            for (int e = 0; e < PX; e++) M[m2][e + 1] = -1; // rows outside the image are skipped by NMS
         }
         // edge pixels of the neighbouring lanes (lanes 0 and 63 get 0 here; they are halo lanes whose
-        // own NMS results are never stored, and their neighbours only read M[8] / M[1] from them)
-        M[m2][0] = (int)from_left((uint32_t)M[m2][8]);
-        M[m2][9] = (int)from_right((uint32_t)M[m2][1]);
+        // own NMS results are never stored, and their neighbours only read M[PX] / M[1] from them)
+        M[m2][0] = (int)from_left((uint32_t)M[m2][PX]);
+        M[m2][PX + 1] = (int)from_right((uint32_t)M[m2][1]);
 
         // ---- NMS for row y2 = r-2 ---------------------------------------------------------------
         const int y2 = r - 2;
         if (y2 >= ybeg && y2 < yend) {
-            uint32_t outp[4] = {0u, 0u, 0u, 0u}; // suppressed magnitudes as s16 pairs (pixel 2i, pixel 2i+1)
+            uint32_t outp[NP] = {}; // suppressed magnitudes as s16 pairs (pixel 2i, pixel 2i+1)
             unsigned cbits = 0, sbits = 0;
 #pragma unroll
-            for (int ee = 0; ee < 8; ee++) {
-                const int e = PLANES ? 7 - ee : ee; // planes: pixel 7 first, so that pixel e ends up in bit e
+            for (int ee = 0; ee < PX; ee++) {
+                const int e = PLANES ? PX - 1 - ee : ee; // planes: last pixel first, so that pixel e ends up in bit e
                 const int c = e + 1;
                 const int mc = M[m1][c];
                 // PLANES: min_val - 1 rides along as the third operand of a v_max3_i32 -- no extra instruction
@@ -279,32 +277,35 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
                 }
             }
             if (PLANES) {
-                if (owner) { // W % 8 == 0: an owner lane's 8 pixels are all inside the image
-                    const unsigned bx = (unsigned)x0 >> 3;
-                    const unsigned off = ((unsigned)(y2 >> 6) * (unsigned)jb.tiles_x + (bx >> 3)) * 512u +
-                                         (unsigned)(y2 & 63) * 8u + (bx & 7u);
-                    const unsigned sb = sbits & cbits;
-                    jb.pconn[off] = (uint8_t)cbits;
-                    jb.pstrong[off] = (uint8_t)sb;
-                    // Provisional edge map: strong pixels already carry their final value, everything else 0;
-                    // the propagation sweeps add the weak pixels they promote.  These 2 B/px ride along for
-                    // free (the kernel is VALU bound) and replace the separate finalize pass.
-                    const uint32_t tb = sb | (sb << 15); // bit 2k -> bit 0, bit 2k+1 -> bit 16 of pair k
-                    uint4 v;
-                    v.x = __umul24(tb & 0x00010001u, (uint32_t)jb.edge_value);
-                    v.y = __umul24((tb >> 2) & 0x00010001u, (uint32_t)jb.edge_value);
-                    v.z = __umul24((tb >> 4) & 0x00010001u, (uint32_t)jb.edge_value);
-                    v.w = __umul24((tb >> 6) & 0x00010001u, (uint32_t)jb.edge_value);
-                    __builtin_memcpy(jb.fout + (size_t)y2 * W + x0, &v, 16);
+                // Provisional edge map: strong pixels already carry their final value, everything else 0; the
+                // propagation sweeps add the weak pixels they promote (this replaces the finalize pass).
+                unsigned sb = sbits & cbits;
+                const uint32_t tb = sb | (sb << 15); // bit 2k -> bit 0, bit 2k+1 -> bit 16 of pair k
+#pragma unroll
+                for (int i = 0; i < NP; i++) outp[i] = __umul24((tb >> (2 * i)) & 0x00010001u, (uint32_t)jb.edge_value);
+                if (NP == 2) {
+                    // 4 pixels are half a plane byte: odd lanes hold the low nibble (x0 % 8 == 0) and fetch the high
+                    // one from their right neighbour; lanes 1..62 pair up exactly (1,2) .. (61,62)
+                    cbits |= from_right(cbits) << 4;
+                    sb |= from_right(sb) << 4;
+                }
+                if (owner) { // W % 8 == 0: an owner lane's pixels are all inside the image
+                    if (NP == 4 || (jb.lane & 1)) {
+                        const unsigned bx = (unsigned)x0 >> 3;
+                        const unsigned off = ((unsigned)(y2 >> 6) * (unsigned)jb.tiles_x + (bx >> 3)) * 512u +
+                                             (unsigned)(y2 & 63) * 8u + (bx & 7u);
+                        jb.pconn[off] = (uint8_t)cbits;
+                        jb.pstrong[off] = (uint8_t)sb;
+                    }
+                    __builtin_memcpy(jb.fout + (size_t)y2 * W + x0, outp, 4 * NP);
                 }
             } else if (owner) {
                 int16_t *dst = jb.fout + (size_t)y2 * W + x0;
                 if (!COL_EDGE || full8) {
-                    const uint4 v = make_uint4(outp[0], outp[1], outp[2], outp[3]);
-                    __builtin_memcpy(dst, &v, 16);
+                    __builtin_memcpy(dst, outp, 4 * NP);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; e++)
+                    for (int e = 0; e < PX; e++)
                         if (x0 + e < W) dst[e] = (int16_t)(outp[e >> 1] >> (16 * (e & 1)));
                 }
             }
@@ -316,7 +317,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
     // dispatcher guarantees that even the extra rows and the two prefetched ones lie inside the image.
     const int rfirst = ybeg - 2;
     const int rlast = rfirst + 3 * ((yend + 1 - rfirst + 3) / 3) - 1;
-    uint32_t pa[4], pb[4], pc[4]; // software prefetch: rows r, r+1, r+2 -- renamed, never copied
+    uint32_t pa[NP], pb[NP], pc[NP]; // software prefetch: rows r, r+1, r+2 -- renamed, never copied
     load_row(rfirst, pa);
     load_row(rfirst + 1, pb);
     for (int r = rfirst; r <= rlast; r += 3) {
@@ -336,7 +337,7 @@ struct PlaneArgs { // PLANES instantiation only
     int tiles_x, tiles_y, lo1, hi1, edge_value;
 };
 
-template <bool PLANES>
+template <bool PLANES, int NP>
 __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int16_t *__restrict__ in,
                                                                        int16_t *__restrict__ out, int H, int W,
                                                                        int n_strips, int n_segs, int seg_rows,
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
     jb.W = W;
     jb.ybeg = g * seg_rows;
     jb.yend = min(H, jb.ybeg + seg_rows);
-    jb.x0 = s * SNM_SW + (jb.lane - 1) * SNM_PX; // column of this lane's pixel 0
+    jb.x0 = s * SnmCfg<NP>::SW + (jb.lane - 1) * SnmCfg<NP>::PX; // column of this lane's pixel 0
     jb.fin = in + (size_t)f * H * W;
     jb.fout = out + (size_t)f * H * W; // PLANES: the provisional edge map
     if (PLANES) {
@@ -368,30 +369,35 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
         jb.hi1 = pl.hi1;
     }
     // first strip: column 0 and the out-of-image halo lane; last strip: column W-1 and columns >= W
-    const bool col_edge = (s == 0) || ((s + 1) * SNM_SW + SNM_PX >= W);
+    const bool col_edge = (s == 0) || ((s + 1) * SnmCfg<NP>::SW + SnmCfg<NP>::PX >= W);
     // rows touched: ybeg-2 .. (rounded-up last row) + 2 prefetched  <=  yend + 5
     const bool row_edge = (jb.ybeg < 2) || (jb.yend + 5 >= H);
     if (col_edge) {
         if (row_edge)
-            march_strip<true, true, PLANES>(jb);
+            march_strip<true, true, PLANES, NP>(jb);
         else
-            march_strip<true, false, PLANES>(jb);
+            march_strip<true, false, PLANES, NP>(jb);
     } else {
         if (row_edge)
-            march_strip<false, true, PLANES>(jb);
+            march_strip<false, true, PLANES, NP>(jb);
         else
-            march_strip<false, false, PLANES>(jb);
+            march_strip<false, false, PLANES, NP>(jb);
     }
 }
 
 bool sobel_nms_march_supported(int height, int width) { return height >= 2 && width >= 2; }
+
+static int px_variant = 0; // A/B switch "tune_sobel_px": 0 = 8 pixels per lane, 1 = 4 pixels per lane
+void sobel_nms_set_px_variant(int v) { px_variant = v; }
 
 // tune_seg: 0 = automatic, else rows per segment (A/B knob).  tune_prefetch is accepted for ABI stability of
 // the option and ignored: a 5-row prefetch distance measured identical to 2 rows (the kernel is VALU bound).
 static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const PlaneArgs *planes, int height, int width,
                                int n_frames, hipStream_t stream, int tune_seg)
 {
-    int n_strips = (width + SNM_SW - 1) / SNM_SW;
+    const int np = px_variant == 1 ? 2 : 4;
+    const int sw = 62 * 2 * np;
+    int n_strips = (width + sw - 1) / sw;
     int seg = 256;
     while (seg > 32 && (long long)n_frames * n_strips * ((height + seg - 1) / seg) < 16384) seg >>= 1;
     if (tune_seg >= 8) seg = tune_seg;
@@ -399,12 +405,20 @@ static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const Plan
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;
     unsigned blocks = (unsigned)((waves + SNM_WPB - 1) / SNM_WPB);
-    if (planes)
-        hipLaunchKernelGGL(sobel_nms_march_kernel<true>, dim3(blocks), dim3(SNM_WPB * 64), 0, stream, smoothed, out,
-                           height, width, n_strips, n_segs, seg, (int)waves, *planes);
+    const PlaneArgs pl = planes ? *planes : PlaneArgs{};
+    const dim3 grid(blocks), block(SNM_WPB * 64);
+    if (planes && np == 4)
+        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 4>), grid, block, 0, stream, smoothed, out, height, width,
+                           n_strips, n_segs, seg, (int)waves, pl);
+    else if (planes)
+        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 2>), grid, block, 0, stream, smoothed, out, height, width,
+                           n_strips, n_segs, seg, (int)waves, pl);
+    else if (np == 4)
+        hipLaunchKernelGGL((sobel_nms_march_kernel<false, 4>), grid, block, 0, stream, smoothed, out, height, width,
+                           n_strips, n_segs, seg, (int)waves, pl);
     else
-        hipLaunchKernelGGL(sobel_nms_march_kernel<false>, dim3(blocks), dim3(SNM_WPB * 64), 0, stream, smoothed, out,
-                           height, width, n_strips, n_segs, seg, (int)waves, PlaneArgs{});
+        hipLaunchKernelGGL((sobel_nms_march_kernel<false, 2>), grid, block, 0, stream, smoothed, out, height, width,
+                           n_strips, n_segs, seg, (int)waves, pl);
     return hipGetLastError();
 }
 

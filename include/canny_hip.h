@@ -95,6 +95,7 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "fuse_classify": 1 (default) / 0 -- canny(): the Sobel+NMS kernel writes the hysteresis bit-planes itself
  *                    (used when width % 8 == 0 and min_val >= 1; otherwise the separate kernels run)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
+ *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide)
  *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel with the row-pass product table in LDS,
  *                    1 LDS-ring marching kernel, 2 symmetric-tap kernel that multiplies (process-wide)
  *   "tune_gaussian_seg": approximate rows per wave segment of the marching Gaussian, 0 = automatic (process-wide)

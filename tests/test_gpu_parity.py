@@ -407,11 +407,21 @@ def test_gaussian_half_windows_covered():
     assert centers == list(range(1, 9)), centers
 
 
+@pytest.fixture(params=[0, 1], ids=["8px_per_lane", "4px_per_lane"])
+def sobel_px(hip, request):
+    """Runs a test once per variant of the marching Sobel+NMS kernel (process-wide A/B switch)."""
+    with hip.Context(0) as c:
+        c.set_option("tune_sobel_px", request.param)
+    yield request.param
+    with hip.Context(0) as c:
+        c.set_option("tune_sobel_px", 0)
+
+
 @pytest.mark.parametrize("path", [1, 2])
-def test_sobel_nms_paths(hip, path):
+def test_sobel_nms_paths(hip, path, sobel_px):
     with hip.Context(0) as c:
         c.set_option("sobel_nms_path", path)
-        for shape in PATH_SHAPES + [(2, 3), (5, 8), (9, 9), (40, 1489), (600, 130)]:
+        for shape in PATH_SHAPES + [(2, 3), (5, 8), (9, 9), (40, 1489), (600, 130), (70, 2000)]:
             h, w = shape
             for seed in (7, 8, 9):
                 sm = oracle.gaussian(_mixed(h, w, seed) if seed != 9 else _noise(h, w, seed), 0.5)
@@ -440,7 +450,7 @@ FUSE_THRESHOLDS = [(50, 150), (1, 1), (1, 5000), (100, 50), (20, 20), (255, 256)
 
 @pytest.mark.parametrize("fuse", [0, 1])
 @pytest.mark.parametrize("lo,hi", FUSE_THRESHOLDS)
-def test_canny_fused_classify(hip, fuse, lo, hi):
+def test_canny_fused_classify(hip, fuse, lo, hi, sobel_px):
     with hip.Context(0) as c:
         c.set_option("fuse_classify", fuse)
         for h, w in FUSE_SHAPES:

@@ -61,6 +61,21 @@ def main():
         print(f"  {name:14s} median {med:.4f} ms  min {mn:.4f} ms   {alg / med / 1e6:.0f} GB/s  ({alg / med / 8e9 * 100:.1f}% of 8 TB/s)")
     ctx.set_option("tune_sobel_seg", 0)
 
+    # 8 vs 4 pixels per lane: s16 kernel alone and the fused kernel inside canny()
+    pres = {}
+    for _ in range(args.rounds):
+        for px in (0, 1):
+            ctx.set_option("tune_sobel_px", px)
+            pres.setdefault(("s16", px), []).append(
+                time_stage(lambda: ctx.dev_sobel_nms(d_sm, H, W, F, d_out), capi.STAGE_SOBEL_NMS))
+            ctx.profile_reset()
+            ctx.dev_canny(d_img, args.sigma, 50, 150, H, W, F, d_out)
+            ctx.synchronize()
+            pres.setdefault(("fused", px), []).append(ctx.profile_get(capi.STAGE_SOBEL_NMS)[0])
+    ctx.set_option("tune_sobel_px", 0)
+    for (kind, px), v in sorted(pres.items()):
+        print(f"Sobel+NMS {kind:5s} {'4' if px else '8'} px/lane: median {statistics.median(v):.4f} ms  min {min(v):.4f} ms")
+
     gmodes = [(variant, fma) for variant in (0, 2, 1) for fma in (0, 1)]
     gres = {m: [] for m in gmodes}
     for _ in range(args.rounds):

@@ -38,7 +38,7 @@ EXPORTS = (
     "canny_hip_host_alloc", "canny_hip_host_free", "canny_hip_memcpy_h2d", "canny_hip_memcpy_d2h",
     "canny_hip_gaussian_kernel", "canny_hip_gaussian", "canny_hip_xy_gradient", "canny_hip_sobel", "canny_hip_nms",
     "canny_hip_hysteresis", "canny_hip_find_edge_pixels", "canny_hip_canny", "canny_hip_canny_batch",
-    "canny_hip_canny_multi_gpu", "canny_hip_shard_range", "canny_hip_dev_gaussian", "canny_hip_dev_xy_gradient",
+    "canny_hip_canny_batch_u8", "canny_hip_dev_canny_u8", "canny_hip_canny_multi_gpu", "canny_hip_shard_range", "canny_hip_dev_gaussian", "canny_hip_dev_xy_gradient",
     "canny_hip_dev_sobel", "canny_hip_dev_nms", "canny_hip_dev_sobel_nms", "canny_hip_dev_hysteresis",
     "canny_hip_dev_canny", "canny_hip_profile_enable", "canny_hip_profile_reset", "canny_hip_profile_get",
     "canny_hip_selftest_mag_angle", "canny_hip_selftest_div", "canny_hip_selftest_div_fma",
@@ -95,6 +95,8 @@ def load() -> C.CDLL:
         "canny_hip_find_edge_pixels": ([p, p, p, i, i, i, i, i], i),
         "canny_hip_canny": ([p, p, f, i, i, i, i, p], i),
         "canny_hip_canny_batch": ([p, p, i, f, i, i, i, i, p], i),
+        "canny_hip_canny_batch_u8": ([p, p, i, f, i, i, i, i, p], i),
+        "canny_hip_dev_canny_u8": ([p, p, f, i, i, i, i, i, p], i),
         "canny_hip_canny_multi_gpu": ([p, i, f, i, i, i, i, p, i], i),
         "canny_hip_shard_range": ([i, i, i, ip, ip], i),
         "canny_hip_dev_gaussian": ([p, p, f, i, i, i, p], i),
@@ -306,16 +308,21 @@ class Context:
         buf = (C.c_uint8 * nbytes).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
-    def canny_batch(self, imgs, sigma: float, min_val: int, max_val: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+    def canny_batch(self, imgs, sigma: float, min_val: int, max_val: int, out: Optional[np.ndarray] = None,
+                    u8: bool = False) -> np.ndarray:
+        """Host frames in, host edge maps out, transfers overlapped with the kernels.  u8=True returns the maps as
+        uint8 (0 / 255) instead of the reference's int16: a third less PCIe traffic."""
         a = np.ascontiguousarray(imgs, dtype=np.uint8)
         if a.ndim != 3:
             raise ValueError("expected uint8 [n_frames, H, W]")
+        dtype = np.uint8 if u8 else np.int16
         if out is None:
-            out = np.empty(a.shape, np.int16)
-        elif out.shape != a.shape or out.dtype != np.int16 or not out.flags["C_CONTIGUOUS"]:
-            raise ValueError("out must be a C-contiguous int16 array of the input's shape")
-        self._check(self._L.canny_hip_canny_batch(self._h, _hp(a), a.shape[0], sigma, min_val, max_val, a.shape[1],
-                                                  a.shape[2], _hp(out)), "canny_batch")
+            out = np.empty(a.shape, dtype)
+        elif out.shape != a.shape or out.dtype != dtype or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of the input's shape")
+        fn = self._L.canny_hip_canny_batch_u8 if u8 else self._L.canny_hip_canny_batch
+        self._check(fn(self._h, _hp(a), a.shape[0], sigma, min_val, max_val, a.shape[1], a.shape[2], _hp(out)),
+                    "canny_batch")
         return out
 
     def selftest_mag_angle(self, lim: int = 1020):
@@ -367,6 +374,10 @@ class Context:
     def dev_canny(self, d_img: int, sigma: float, min_val: int, max_val: int, h: int, w: int, n: int, d_edges: int):
         self._check(self._L.canny_hip_dev_canny(self._h, C.c_void_p(d_img), sigma, min_val, max_val, h, w, n,
                                                 C.c_void_p(d_edges)), "dev_canny")
+
+    def dev_canny_u8(self, d_img: int, sigma: float, min_val: int, max_val: int, h: int, w: int, n: int, d_edges: int):
+        self._check(self._L.canny_hip_dev_canny_u8(self._h, C.c_void_p(d_img), sigma, min_val, max_val, h, w, n,
+                                                   C.c_void_p(d_edges)), "dev_canny_u8")
 
 
 def canny_multi_gpu(imgs, sigma: float, min_val: int, max_val: int, n_devices: int = 0) -> np.ndarray:

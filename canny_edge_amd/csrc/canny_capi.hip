@@ -76,6 +76,7 @@ struct canny_hip_ctx {
     // device workspaces
     DevBuf tmp_f32;   // generic Gaussian row-pass plane
     DevBuf smoothed;  // pipeline: Gaussian output
+    DevBuf edges16;   // canny_hip_dev_canny_u8: the s16 edge map before narrowing
     DevBuf plane_s, plane_c, stamps, flags; // hysteresis bit-planes / scheduling words
     DevBuf io[4];     // staging for the host-pointer stage functions
     unsigned *host_flags = nullptr;     // pinned + mapped, 4 words: last_change, domain, sequence number, spare
@@ -427,6 +428,7 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
     ctx->smoothed.release();
     ctx->plane_s.release();
     ctx->plane_c.release();
+    ctx->edges16.release();
     ctx->stamps.release();
     ctx->flags.release();
     for (auto &b : ctx->io) b.release();
@@ -688,8 +690,9 @@ int canny_hip_shard_range(int n_frames, int rank, int world, int *begin, int *en
 // Stream-overlapped batch: the frames are cut into chunks; up to three worker threads, each with its
 // own stream, device workspace and pinned staging, take chunks round-robin so that the H2D copy of
 // one chunk, the kernels of another and the D2H copy of a third are in flight together.
-int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
-                          int max_val, int height, int width, short *edges)
+// out_u8: `edges` is an unsigned char plane per frame (0 / 255) instead of a short plane.
+static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                            int max_val, int height, int width, void *edges, bool out_u8)
 {
     int rc = bind(ctx);
     if (rc) return rc;
@@ -724,15 +727,17 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
             return;
         }
         unsigned char *pin_in = nullptr;
-        short *pin_out = nullptr;
-        void *d_in = nullptr, *d_out = nullptr;
-        const size_t in_bytes = frame_px * chunk, out_bytes = frame_px * chunk * sizeof(short);
+        unsigned char *pin_out = nullptr;
+        void *d_in = nullptr, *d_out = nullptr, *d_out8 = nullptr;
+        const size_t out_elem = out_u8 ? 1 : sizeof(short);
+        const size_t in_bytes = frame_px * chunk, out_bytes = frame_px * chunk * out_elem;
         hipError_t e = hipSuccess;
         // pageable caller buffers are staged through pinned memory; pinned ones are DMA'd in place
         if (!in_pinned) e = hipHostMalloc((void **)&pin_in, in_bytes);
         if (e == hipSuccess && !out_pinned) e = hipHostMalloc((void **)&pin_out, out_bytes);
         if (e == hipSuccess) e = hipMalloc(&d_in, in_bytes);
-        if (e == hipSuccess) e = hipMalloc(&d_out, out_bytes);
+        if (e == hipSuccess) e = hipMalloc(&d_out, frame_px * chunk * sizeof(short));
+        if (e == hipSuccess && out_u8) e = hipMalloc(&d_out8, out_bytes);
         if (e != hipSuccess) {
             status[wid] = fail(sub, e, "batch staging allocation");
         } else {
@@ -754,15 +759,24 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
                     status[wid] = st;
                     break;
                 }
-                short *dst = edges + (size_t)f0 * frame_px;
-                e = hipMemcpyAsync(out_pinned ? dst : pin_out, d_out, frame_px * nf * sizeof(short),
-                                   hipMemcpyDeviceToHost, sub->stream);
+                const void *d_res = d_out;
+                if (out_u8) { // narrow on the device: the D2H copy is what this variant is for
+                    e = launch_edges_to_u8((const int16_t *)d_out, (uint8_t *)d_out8, frame_px * nf, sub->stream);
+                    if (e != hipSuccess) {
+                        status[wid] = fail(sub, e, "batch u8 narrowing");
+                        break;
+                    }
+                    d_res = d_out8;
+                }
+                unsigned char *dst = (unsigned char *)edges + (size_t)f0 * frame_px * out_elem;
+                e = hipMemcpyAsync(out_pinned ? dst : pin_out, d_res, frame_px * nf * out_elem, hipMemcpyDeviceToHost,
+                                   sub->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(sub->stream);
                 if (e != hipSuccess) {
                     status[wid] = fail(sub, e, "batch D2H");
                     break;
                 }
-                if (!out_pinned) std::memcpy(dst, pin_out, frame_px * nf * sizeof(short));
+                if (!out_pinned) std::memcpy(dst, pin_out, frame_px * nf * out_elem);
             }
         }
         if (status[wid] != CANNY_HIP_OK) errors[wid] = sub->last_error;
@@ -770,6 +784,7 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
         if (pin_out) (void)hipHostFree(pin_out);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
+        if (d_out8) (void)hipFree(d_out8);
         canny_hip_ctx_destroy(sub);
     };
     std::vector<std::thread> threads;
@@ -782,6 +797,18 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
             return status[i];
         }
     return CANNY_HIP_OK;
+}
+
+int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                          int max_val, int height, int width, short *edges)
+{
+    return canny_batch_impl(ctx, imgs, n_frames, sigma, min_val, max_val, height, width, edges, false);
+}
+
+int canny_hip_canny_batch_u8(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                             int max_val, int height, int width, unsigned char *edges)
+{
+    return canny_batch_impl(ctx, imgs, n_frames, sigma, min_val, max_val, height, width, edges, true);
 }
 
 int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
@@ -895,6 +922,21 @@ int canny_hip_dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float si
     if (!d_img || !d_edges) return CANNY_HIP_ERR_INVALID;
     if ((rc = check_dims(height, width, n_frames))) return rc;
     return dev_canny(ctx, d_img, sigma, min_val, max_val, height, width, n_frames, d_edges);
+}
+
+int canny_hip_dev_canny_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
+                           int height, int width, int n_frames, unsigned char *d_edges)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_img || !d_edges) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    const size_t n = npx(height, width, n_frames);
+    HIP_TRY(ctx, ctx->edges16.ensure(n * sizeof(short)));
+    if ((rc = dev_canny(ctx, d_img, sigma, min_val, max_val, height, width, n_frames, (short *)ctx->edges16.p)))
+        return rc;
+    HIP_TRY(ctx, launch_edges_to_u8((const int16_t *)ctx->edges16.p, d_edges, n, ctx->stream));
+    return CANNY_HIP_OK;
 }
 
 // ---- profiling --------------------------------------------------------------------------------------

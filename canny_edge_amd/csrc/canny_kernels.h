@@ -101,6 +101,8 @@ hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom 
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
                                  int iter, const HystGeom &g, hipStream_t stream, int16_t *edges = nullptr,
                                  int edge_value = 0);
+// s16 edge map (0 / 255) -> u8, n pixels.
+hipError_t launch_edges_to_u8(const int16_t *edges, uint8_t *out, size_t n, hipStream_t stream);
 // Copies flags[0..1] (last_change, domain) to host_flags_dev[0..1] and then stores seq to host_flags_dev[2]
 // (system-scope release); host_flags_dev is the device view of pinned, mapped host memory.
 hipError_t launch_hyst_publish(const unsigned *flags, unsigned *host_flags_dev, unsigned seq, hipStream_t stream);

@@ -840,6 +840,39 @@ hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom 
     return hipGetLastError();
 }
 
+// s16 edge map (values 0 / 255) -> u8: the low byte of every pixel.  16 pixels per thread where alignment
+// allows (two 16-byte loads, one 16-byte store), scalar head and tail otherwise.
+__global__ __launch_bounds__(256) void edges_to_u8_kernel(const int16_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                          size_t n)
+{
+    const size_t groups = n / 16;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 15u) == 0;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
+        if (aligned) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(in + g * 16);
+            const uint4 b = *reinterpret_cast<const uint4 *>(in + g * 16 + 8);
+            // bytes 0 and 2 of each dword are the low bytes of its two pixels
+            uint4 r;
+            r.x = __builtin_amdgcn_perm(a.y, a.x, 0x06040200u);
+            r.y = __builtin_amdgcn_perm(a.w, a.z, 0x06040200u);
+            r.z = __builtin_amdgcn_perm(b.y, b.x, 0x06040200u);
+            r.w = __builtin_amdgcn_perm(b.w, b.z, 0x06040200u);
+            *reinterpret_cast<uint4 *>(out + g * 16) = r;
+        } else {
+            for (int k = 0; k < 16; k++) out[g * 16 + k] = (uint8_t)in[g * 16 + k];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n % 16) out[groups * 16 + threadIdx.x] = (uint8_t)in[groups * 16 + threadIdx.x];
+}
+
+hipError_t launch_edges_to_u8(const int16_t *edges, uint8_t *out, size_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(edges_to_u8_kernel, dim3(grid_for(n / 16 + 1, 256)), dim3(256), 0, stream, edges, out, n);
+    return hipGetLastError();
+}
+
 // Publishes flags[0..1] and a sequence number in host-visible (pinned, mapped) memory: the host polls host[2].
 __global__ void hyst_publish_kernel(const unsigned *__restrict__ flags, unsigned *host, unsigned seq)
 {

@@ -139,6 +139,12 @@ int canny_hip_canny(canny_hip_ctx *ctx, const unsigned char *img, float sigma, i
  * overlap on separate streams with pinned staging (BASELINE config 3). */
 int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
                           int max_val, int height, int width, short *edges);
+/* Same, but the edge maps come back as 8-bit planes (NOEDGE = 0, EDGE = 255: the values of src/utils.h:5-6
+ * fit a byte).  Not in the reference: its edge map is the s16 plane hysteresis() works in (src/utils.cpp:478);
+ * over PCIe that plane is two thirds of all bytes moved, so batches that only need the final map should take
+ * this one. */
+int canny_hip_canny_batch_u8(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                             int max_val, int height, int width, unsigned char *edges);
 /* Shards n_frames by contiguous ranges over n_devices GPUs (devices 0..n_devices-1), one host
  * thread and one context per GPU, no collective (BASELINE config 5).  n_devices <= 0 = all. */
 int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
@@ -166,6 +172,10 @@ int canny_hip_dev_hysteresis(canny_hip_ctx *ctx, short *d_edge_candidates, int h
 /* gaussian -> fused sobel+nms -> hysteresis over n_frames resident frames. */
 int canny_hip_dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
                         int height, int width, int n_frames, short *d_edges);
+/* Same with an 8-bit edge map (0 / 255) as output; the s16 map is kept in a context workspace and narrowed
+ * by one more elementwise kernel (this entry point exists for transfers, not for speed on the device). */
+int canny_hip_dev_canny_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
+                           int height, int width, int n_frames, unsigned char *d_edges);
 
 /* ---- per-stage HIP-event timing (events are recorded on the launch stream) ----------------- */
 int canny_hip_profile_enable(canny_hip_ctx *ctx, int on);

@@ -358,6 +358,34 @@ def test_batch_and_multi_gpu_entry_points(ctx, hip):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(120, 200), (33, 37), (64, 1024), (5, 7)])
+def test_u8_edge_maps(ctx, shape):
+    """The 8-bit edge-map entry points (batch over PCIe and device-resident) carry the same 0 / 255 maps."""
+    h, w = shape
+    frames = np.stack([_mixed(h, w, 60 + i) for i in range(5)])
+    want = np.stack([oracle.canny(f, 1.0, 50, 150) for f in frames])
+    assert set(np.unique(want)) <= {0, 255}
+    got = ctx.canny_batch(frames, 1.0, 50, 150, u8=True)
+    assert got.dtype == np.uint8 and np.array_equal(got.astype(np.int16), want)
+    pinned_in = ctx.pinned_array(frames.shape, np.uint8)
+    pinned_out = ctx.pinned_array(frames.shape, np.uint8)
+    pinned_in[...] = frames
+    pinned_out[...] = 7
+    assert ctx.canny_batch(pinned_in, 1.0, 50, 150, out=pinned_out, u8=True) is pinned_out
+    assert np.array_equal(pinned_out.astype(np.int16), want)
+    d_in, d_out = ctx.malloc(frames.nbytes), ctx.malloc(frames.nbytes + 3)
+    try:
+        ctx.h2d(d_in, frames)
+        for shift in (0, 1):  # aligned and unaligned output (the narrowing kernel has a scalar path)
+            ctx.dev_canny_u8(d_in, 1.0, 50, 150, h, w, 5, d_out + shift)
+            got = np.empty(frames.shape, np.uint8)
+            ctx.d2h(got, d_out + shift)
+            assert np.array_equal(got.astype(np.int16), want), shift
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+
+
 def test_stage_profile_counts_launches(ctx):
     img = _mixed(200, 300, 40)
     ctx.profile_enable(True)

@@ -8,13 +8,17 @@
 // entry point (cuda_canny) instead of canny().  In this build both run on the MI355X.
 // Replaced: VideoCapture(0) 640x480 (:78-115) -> a binary PGM given with -i, or a synthetic frame
 // of the webcam's size (-n overrides the size); imshow -> PGM files in the -o directory.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <filesystem>
 #include <fstream>
 #include <iostream>
 #include <string>
 #include <vector>
 
+#include "canny_hip.h"
 #include "utils.h"
 #include "cuda.h"
 
@@ -74,6 +78,70 @@ static void synthetic_frame(vector<unsigned char> &px, int height, int width)
     }
 }
 
+static bool write_pgm(const string &path, const unsigned char *px, int height, int width)
+{
+    ofstream f(path, ios::binary);
+    if (!f) return false;
+    f << "P5\n" << width << " " << height << "\n255\n";
+    f.write((const char *)px, (streamsize)((size_t)width * height));
+    return (bool)f;
+}
+
+// -b dir: every *.pgm of the directory (sorted by name, all of one size) goes through the stream-overlapped
+// batch entry point in one call; the 0/255 edge maps come back as bytes and are written as <name>_edges.pgm.
+// The reference has no such mode (it loops over webcam frames, src/main.cpp:120-137); SURVEY.md 8(f) item 1.
+static int run_batch(const string &dir, const string &outdir, float sigma, int minVal, int maxVal)
+{
+    namespace fs = std::filesystem;
+    vector<fs::path> files;
+    error_code ec;
+    for (const auto &e : fs::directory_iterator(dir, ec))
+        if (e.is_regular_file() && e.path().extension() == ".pgm") files.push_back(e.path());
+    if (ec || files.empty()) {
+        cout << "ERROR: no .pgm frames in " << dir << endl;
+        return -1;
+    }
+    sort(files.begin(), files.end());
+    int height = 0, width = 0;
+    vector<unsigned char> frames, one;
+    for (size_t i = 0; i < files.size(); i++) {
+        int h = 0, w = 0;
+        if (!read_pgm(files[i].string(), one, h, w) || (i > 0 && (h != height || w != width))) {
+            cout << "ERROR: Failed to open " << files[i].string() << " (or its size differs from the first frame)" << endl;
+            return -1;
+        }
+        height = h;
+        width = w;
+        frames.insert(frames.end(), one.begin(), one.end());
+    }
+    const size_t frame_px = (size_t)height * width;
+    vector<unsigned char> edges(frames.size());
+    canny_hip_ctx *ctx = nullptr;
+    int st = canny_hip_ctx_create(&ctx, 0);
+    const auto t0 = chrono::steady_clock::now();
+    if (!st)
+        st = canny_hip_canny_batch_u8(ctx, frames.data(), (int)files.size(), sigma, minVal, maxVal, height, width,
+                                      edges.data());
+    const chrono::duration<double> dt = chrono::steady_clock::now() - t0;
+    if (st) {
+        fprintf(stderr, "ERROR: %s\n", ctx ? canny_hip_last_error(ctx) : canny_hip_status_string(st));
+        if (ctx) canny_hip_ctx_destroy(ctx);
+        return 1;
+    }
+    canny_hip_ctx_destroy(ctx);
+    const fs::path out = outdir.empty() ? fs::path(dir) : fs::path(outdir);
+    for (size_t i = 0; i < files.size(); i++) {
+        const fs::path dst = out / (files[i].stem().string() + "_edges.pgm");
+        if (!write_pgm(dst.string(), edges.data() + i * frame_px, height, width)) {
+            cout << "ERROR: Failed to write " << dst.string() << endl;
+            return -1;
+        }
+    }
+    cout << "Execution time: " << dt.count() << " seconds (" << files.size() << " frames of " << width << "x" << height
+         << ")\n";
+    return 0;
+}
+
 int main(int argc, char *argv[])
 {
     float sigma;
@@ -81,7 +149,7 @@ int main(int argc, char *argv[])
     int maxVal;
     bool use_gpu_entry = false;
     bool show_steps = false;
-    string input, outdir;
+    string input, outdir, batch_dir;
     int width = WIDTH, height = HEIGHT;
     vector<string> values;
 
@@ -95,6 +163,8 @@ int main(int argc, char *argv[])
             input = argv[++i];
         } else if (arg == "-o" && i + 1 < argc) {
             outdir = argv[++i];
+        } else if (arg == "-b" && i + 1 < argc) {
+            batch_dir = argv[++i];
         } else if (arg == "-n" && i + 1 < argc) {
             if (sscanf(argv[++i], "%dx%d", &width, &height) != 2 || width < 2 || height < 2) {
                 fprintf(stderr, "ERROR: -n expects WIDTHxHEIGHT\n");
@@ -114,6 +184,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "           Must be in the range of [0,255]\n");
         fprintf(stderr, "   -c: use the GPU entry point (cuda_canny)   -s: write every step\n");
         fprintf(stderr, "   -i in.pgm: input frame (binary PGM)   -n WxH: synthetic frame size   -o dir: output dir\n");
+        fprintf(stderr, "   -b dir: run every .pgm of dir as one batch, write <name>_edges.pgm\n");
         exit(0);
     }
 
@@ -138,6 +209,8 @@ int main(int argc, char *argv[])
         fprintf(stderr, "ERROR: maxVal must be in the range of [0,255]");
         exit(0);
     }
+
+    if (!batch_dir.empty()) return run_batch(batch_dir, outdir, sigma, minVal, maxVal);
 
     vector<unsigned char> frame;
     if (!input.empty()) {

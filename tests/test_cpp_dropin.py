@@ -82,3 +82,21 @@ def test_cli_end_to_end(tmp_path, flags):
         assert np.array_equal(sm, norm)
         assert os.path.exists(tmp_path / "canny_step2_gradient.pgm")
         assert os.path.exists(tmp_path / "canny_step3_nonmaximal.pgm")
+
+
+@pytest.mark.gpu
+def test_cli_batch_directory(tmp_path):
+    """./Main sigma minVal maxVal -b dir: every PGM of the directory in one batch, 8-bit edge maps written back."""
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    dst.mkdir()
+    frames = {f"f{i:02d}": synth_frame(240, 328, 20 + i) for i in range(5)}
+    for name, img in frames.items():
+        _write_pgm(src / f"{name}.pgm", img)
+    r = subprocess.run([os.path.join(PKG, "Main"), "1.0", "40", "120", "-b", str(src), "-o", str(dst)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Execution time:" in r.stdout and "5 frames of 328x240" in r.stdout
+    for name, img in frames.items():
+        got = _read_pgm(dst / f"{name}_edges.pgm")
+        assert np.array_equal(got, oracle.canny(img, 1.0, 40, 120).astype(np.uint8)), name

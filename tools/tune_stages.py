@@ -46,8 +46,8 @@ def main():
 
     # (name, unused dynamic LDS in KB per workgroup [64 KB -> 2 waves/SIMD instead of 3], rows per segment)
     # (name, unused, rows per segment; 0 = the launcher's own choice)
-    configs = [("segauto", 0, 0), ("seg32", 0, 32), ("seg64", 0, 64), ("seg96", 0, 96), ("seg180", 0, 180),
-               ("seg360", 0, 360)]
+    configs = [("segauto", 0, 0), ("seg32", 0, 32), ("seg48", 0, 48), ("seg64", 0, 64), ("seg80", 0, 80),
+               ("seg96", 0, 96), ("seg128", 0, 128), ("seg180", 0, 180), ("seg256", 0, 256), ("seg360", 0, 360)]
     res = {name: [] for name, _, _ in configs}
     for _ in range(args.rounds):
         for name, _unused, seg in configs:

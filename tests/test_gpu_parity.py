@@ -515,3 +515,22 @@ def test_pipeline_paths_batched(hip, gpath, spath):
             c.free(d_in)
             c.free(d_out)
         assert np.array_equal(got, want)
+
+
+def test_canny_unaligned_device_buffers(hip):
+    """Input and output planes that are only 1- / 2-byte aligned (the kernels use 4-, 8- and 16-byte accesses)."""
+    h, w, n = 70, 520, 3
+    frames = np.stack([_mixed(h, w, 90 + i) for i in range(n)])
+    want = np.stack([oracle.canny(f, 1.4, 50, 150) for f in frames])
+    with hip.Context(0) as c:
+        d_in, d_out = c.malloc(frames.nbytes + 64), c.malloc(frames.nbytes * 2 + 64)
+        try:
+            for in_off, out_off in ((1, 2), (3, 6), (5, 14)):
+                c.h2d(d_in + in_off, frames)
+                c.dev_canny(d_in + in_off, 1.4, 50, 150, h, w, n, d_out + out_off)
+                got = np.empty(frames.shape, np.int16)
+                c.d2h(got, d_out + out_off)
+                assert np.array_equal(got, want), (in_off, out_off)
+        finally:
+            c.free(d_in)
+            c.free(d_out)

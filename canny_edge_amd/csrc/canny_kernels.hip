@@ -471,6 +471,11 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
     const bool quirk = (ty == 0 && tx == 0 && lane == 0);
 
     uint64_t s = s0;
+    // closed: s is already closed under the row flood below (it is the result of an earlier flood: every tile
+    // is flooded in sweep 0).  Then a round that adds no pixel from the 8-neighbourhood cannot change anything
+    // and the flood -- two thirds of a round's instructions -- is skipped; every tile's last round is such a one.
+    // (Sweep times did not move: the sweeps are bound by the latency of the tile loads, not by these instructions.)
+    bool closed = iter > 0;
     for (;;) {
         uint64_t up = row_above_u64(s), dn = row_below_u64(s);
         if (lane == 0) up = su;
@@ -479,6 +484,8 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
         uint64_t d_from_left = quirk ? (up | s | (dn & ~1ull)) : d; // what column c may pull from column c-1
         uint64_t nb = d | (d_from_left << 1) | (d >> 1) | in_left | in_right;
         uint64_t gsel = s | (c & nb);
+        if (closed && !__any(gsel != s)) break;
+        closed = true;
         // flood along the row through runs of connectable pixels (Kogge-Stone, both directions)
         uint64_t p = c;
         gsel |= p & (gsel << 1);  p &= p << 1;

@@ -15,13 +15,13 @@ import glob
 import json
 import sys
 
-FRAMES, HEIGHT, WIDTH = 64, 2160, 3840  # bench.py's default workload (what tools/pmc_passes.sh runs)
+FRAMES, HEIGHT, WIDTH = 128, 2160, 3840  # bench.py's default workload (what tools/pmc_passes.sh runs)
 
 KERNELS = {  # key in the JSON -> (substring of the rocprofv3 kernel name, algorithmic bytes per pixel, note)
-    "sobel_nms_classify": ("sobel_nms_march_kernel<true>", 4.25,
+    "sobel_nms_classify": ("sobel_nms_march_kernel<true, 4>", 4.25,
                            "16 B/lane reads (FETCH_SIZE doubled); 16 B/lane edge-map writes (exact) plus the plane "
                            "bytes (raw WRITE_SIZE, 6 % of the writes)"),
-    "sobel_nms": ("sobel_nms_march_kernel<false>", 4.0, "16 B/lane reads (FETCH_SIZE doubled) and writes (exact)"),
+    "sobel_nms": ("sobel_nms_march_kernel<false, 4>", 4.0, "16 B/lane reads (FETCH_SIZE doubled) and writes (exact)"),
 }
 
 

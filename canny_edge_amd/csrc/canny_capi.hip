@@ -70,7 +70,7 @@ struct canny_hip_ctx {
     int last_hyst_iters = 0;
     int gaussian_path = 0;   // 0 auto, 1 generic, 2 march
     int sobel_nms_path = 0;  // 0 auto, 1 LDS tile, 2 march
-    int tune_sobel_prefetch = 0, tune_sobel_seg = 0; // A/B knobs of the marching Sobel+NMS kernel
+    int tune_sobel_seg = 0;  // A/B knob of the marching Sobel+NMS kernel: rows per segment, 0 = automatic
     int fuse_classify = 1;   // canny(): Sobel+NMS emits the hysteresis bit-planes directly when it can
 
     // device workspaces
@@ -309,8 +309,7 @@ int dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int h, int w, int
 {
     StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
     if (ctx->sobel_nms_path != 1 && sobel_nms_march_supported(h, w))
-        HIP_TRY(ctx, launch_sobel_nms_march(d_smoothed, d_out, h, w, n, ctx->stream, ctx->tune_sobel_prefetch,
-                                            ctx->tune_sobel_seg));
+        HIP_TRY(ctx, launch_sobel_nms_march(d_smoothed, d_out, h, w, n, ctx->stream, ctx->tune_sobel_seg));
     else
         HIP_TRY(ctx, launch_sobel_nms(d_smoothed, d_out, h, w, n, /*domain8=*/true, ctx->stream));
     return CANNY_HIP_OK;
@@ -461,8 +460,6 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     if (!ctx || !name || value < 0) return CANNY_HIP_ERR_INVALID;
     if (!std::strcmp(name, "gaussian_path") && value <= 2) ctx->gaussian_path = value;
     else if (!std::strcmp(name, "sobel_nms_path") && value <= 2) ctx->sobel_nms_path = value;
-    else if (!std::strcmp(name, "tune_sobel_prefetch") && (value == 0 || value == 2 || value == 5))
-        ctx->tune_sobel_prefetch = value;
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
     else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
     else if (!std::strcmp(name, "tune_sobel_px") && value <= 1) sobel_nms_set_px_variant(value); // process-wide

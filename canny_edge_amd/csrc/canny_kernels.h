@@ -73,7 +73,7 @@ hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, i
 bool sobel_nms_march_supported(int height, int width);
 void sobel_nms_set_px_variant(int v); // A/B: 0 = 8 pixels per lane, 1 = 4 pixels per lane (more resident waves)
 hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
-                                  hipStream_t stream, int tune_prefetch = 0, int tune_seg = 0);
+                                  hipStream_t stream, int tune_seg = 0);
 
 // Fused Sobel+NMS+classify: the same marching kernel, but instead of the s16 suppressed magnitudes it
 // writes the two hysteresis bit-planes that launch_hyst_classify would derive from them (in-image bytes

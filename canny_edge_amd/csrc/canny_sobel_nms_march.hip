@@ -113,7 +113,8 @@ struct StripJob {
 // W % 8 == 0 (a lane's 8 pixels are one plane byte).  The s16 plane it writes is not the suppressed magnitude
 // but the provisional EDGE MAP (strong -> edge value, else 0), which the propagation sweeps complete in place:
 // the classify pass (2 B/px of loads) and the finalize pass (2 B/px of stores in an HBM-bound kernel) both
-// disappear from the pipeline, and this kernel's own stores hide behind its VALU work.
+// disappear from the pipeline; this kernel pays about +0.1 ms per 64 4K frames for its three stores per row
+// (they do not hide behind the VALU work: see DESIGN.md, "store latency").
 template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP>
 __device__ __forceinline__ void march_strip(const StripJob &jb)
 {
@@ -390,8 +391,7 @@ bool sobel_nms_march_supported(int height, int width) { return height >= 2 && wi
 static int px_variant = 0; // A/B switch "tune_sobel_px": 0 = 8 pixels per lane, 1 = 4 pixels per lane
 void sobel_nms_set_px_variant(int v) { px_variant = v; }
 
-// tune_seg: 0 = automatic, else rows per segment (A/B knob).  tune_prefetch is accepted for ABI stability of
-// the option and ignored: a 5-row prefetch distance measured identical to 2 rows (the kernel is VALU bound).
+// tune_seg: 0 = automatic, else rows per segment (A/B knob).
 static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const PlaneArgs *planes, int height, int width,
                                int n_frames, hipStream_t stream, int tune_seg)
 {
@@ -425,9 +425,8 @@ static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const Plan
 }
 
 hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
-                                  hipStream_t stream, int tune_prefetch, int tune_seg)
+                                  hipStream_t stream, int tune_seg)
 {
-    (void)tune_prefetch;
     return launch_march(smoothed, out, nullptr, height, width, n_frames, stream, tune_seg);
 }
 

@@ -1,7 +1,13 @@
 // canny_gaussian_march.hip -- separable Gaussian, wave-marching path (window <= 17).
 //
-// One WAVE owns a strip of (64-2*HL)*4 output columns and marches down a segment of rows; the waves
-// of a workgroup are independent (no __syncthreads anywhere).  Per input row:
+// Two kernels with the same decomposition (one WAVE owns a strip of (64-2*HL)*4 output columns and marches
+// down a segment of rows, row and column pass in one kernel, the f32 intermediate never leaves the CU):
+//   * gauss_sym_kernel  (default, see the comment above gauss_sym_strip): needs bit-symmetric taps; each
+//     rounded product serves two outputs, the row pass looks its products up in an LDS table and exchanges
+//     them between lanes with DPP, the column pass keeps 2C+1 running sums in registers;
+//   * gauss_march_kernel (below; fallback for asymmetric taps and A/B): LDS row buffer + LDS column ring.
+//
+// gauss_march_kernel: the waves of a workgroup are independent (no __syncthreads anywhere).  Per input row:
 //   1. each lane loads 4 u8 pixels (one dword), converts them once and publishes the 4 floats in a
 //      per-wave LDS row buffer; neighbours' pixels come back as aligned ds_read_b128 (halo exchange
 //      through LDS, wave-scope fences only);

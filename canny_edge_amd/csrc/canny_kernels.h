@@ -43,7 +43,9 @@ inline HystGeom make_hyst_geom(int height, int width, int n_frames)
 // General two-pass path: any window up to kMaxWindow; tmp holds n_frames*H*W floats.
 hipError_t launch_gaussian_generic(const uint8_t *img, float *tmp, int16_t *out, int height, int width,
                                    int n_frames, const GaussTaps &taps, hipStream_t stream);
-// Wave-marching path for center <= 8 (window <= 17): row pass + LDS column ring in one kernel.
+// Wave-marching path for center <= 8 (window <= 17), row and column pass in one kernel: the symmetric-tap
+// kernel (products shared between the +a / -a taps, column sums in registers) or, for asymmetric taps, the
+// LDS-ring kernel (canny_gaussian_march.hip).
 bool gaussian_march_supported(int center, int height, int width);
 hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, int width, int n_frames,
                                  const GaussTaps &taps, hipStream_t stream);

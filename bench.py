@@ -175,12 +175,18 @@ def main():
             measured = {}
 
     def roof(kernel, what, bytes_per_px, ms, launches, extra=None):
+        """ms = device time of this kernel per step, launches = how often it was launched in all timed steps
+        (canny() launches the Sobel+NMS kernel once per half of the batch)."""
+        per_step = max(1, round(launches / max(1, args.steps)))
         alg = bytes_per_px * px_per_step
         ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        m = measured.get(kernel, {})
+        traffic = m.get("hbm_bytes_per_launch") if m.get("frames_per_launch") == F // per_step else None
         r = {"kernel": what, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured.get(kernel, {}).get("hbm_bytes_per_launch"),
-             "algorithmic_bytes_per_px": bytes_per_px, "algorithmic_bytes_per_launch": int(alg),
-             "avg_launch_ms": round(ms, 4), "launches_timed": launches}
+             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+             "algorithmic_bytes_per_px": bytes_per_px, "algorithmic_bytes_per_launch": int(alg / per_step),
+             "avg_launch_ms": round(ms / per_step, 4), "launches_timed": launches, "launches_per_step": per_step,
+             "frames_per_launch": F // per_step}
         if extra:
             r.update(extra)
         return r

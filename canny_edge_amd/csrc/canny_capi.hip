@@ -79,10 +79,17 @@ struct canny_hip_ctx {
     DevBuf edges16;   // canny_hip_dev_canny_u8: the s16 edge map before narrowing
     DevBuf plane_s, plane_c, stamps, flags; // hysteresis bit-planes / scheduling words
     DevBuf io[4];     // staging for the host-pointer stage functions
-    unsigned *host_flags = nullptr;     // pinned + mapped, 4 words: last_change, domain, sequence number, spare
+    unsigned *host_flags = nullptr;     // pinned + mapped, 4 words per lane: last_change, domain, sequence number, spare
     unsigned *host_flags_dev = nullptr; // the same memory as the device sees it
     unsigned publish_seq = 0;           // sequence number of the last launch_hyst_publish
     hipEvent_t flag_event = nullptr;    // recorded behind the publish kernel (fallback wait)
+    // canny(), optional: the propagation of the first half of a batch runs on a second stream, beside the
+    // Sobel+NMS kernel of the second half (the sweeps are latency bound and leave most of the chip idle).  Off by
+    // default: 128 x 4K measured 2.76 ms with it against 2.72 ms without -- the Sobel+NMS kernel loses more
+    // (two half-size launches, sweeps competing for its CUs) than the hidden sweeps give back.
+    int overlap_hysteresis = 0;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t fork_event = nullptr, aux_event = nullptr;
 
     // profiling
     bool prof = false;
@@ -122,7 +129,9 @@ struct StageTimer {
     int stage;
     EventPair ev{};
     bool on = false;
-    StageTimer(canny_hip_ctx *c, int s) : ctx(c), stage(s)
+    hipStream_t stream;
+    StageTimer(canny_hip_ctx *c, int s, hipStream_t on_stream = nullptr)
+        : ctx(c), stage(s), stream(on_stream ? on_stream : c->stream)
     {
         if (!ctx->prof) return;
         if (!ctx->pool.empty()) {
@@ -131,12 +140,12 @@ struct StageTimer {
         } else {
             if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
         }
-        on = hipEventRecord(ev.a, ctx->stream) == hipSuccess;
+        on = hipEventRecord(ev.a, stream) == hipSuccess;
     }
     ~StageTimer()
     {
         if (!on) return;
-        (void)hipEventRecord(ev.b, ctx->stream);
+        (void)hipEventRecord(ev.b, stream);
         ctx->pending[stage].push_back(ev);
     }
 };
@@ -204,14 +213,22 @@ int ensure_hyst(canny_hip_ctx *ctx, const HystGeom &g)
 {
     HIP_TRY(ctx, ctx->plane_s.ensure(g.words() * sizeof(uint64_t)));
     HIP_TRY(ctx, ctx->plane_c.ensure(g.words() * sizeof(uint64_t)));
-    HIP_TRY(ctx, ctx->stamps.ensure(hyst_sched_words(g) * sizeof(unsigned)));
-    HIP_TRY(ctx, ctx->flags.ensure(2 * sizeof(unsigned)));
+    HIP_TRY(ctx, ctx->stamps.ensure((hyst_sched_words(g) + 4) * sizeof(unsigned))); // room for two lanes
+    HIP_TRY(ctx, ctx->flags.ensure(4 * sizeof(unsigned)));
     if (!ctx->host_flags) {
-        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->host_flags, 4 * sizeof(unsigned), hipHostMallocMapped));
-        std::memset(ctx->host_flags, 0, 4 * sizeof(unsigned));
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->host_flags, 8 * sizeof(unsigned), hipHostMallocMapped));
+        std::memset(ctx->host_flags, 0, 8 * sizeof(unsigned));
         HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->host_flags_dev, ctx->host_flags, 0));
     }
     if (!ctx->flag_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->flag_event, hipEventDisableTiming));
+    return CANNY_HIP_OK;
+}
+
+int ensure_aux_stream(canny_hip_ctx *ctx)
+{
+    if (!ctx->aux_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->fork_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+    if (!ctx->aux_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming));
     return CANNY_HIP_OK;
 }
 
@@ -233,48 +250,93 @@ int prepare_hyst(canny_hip_ctx *ctx, const HystGeom &g, bool zero_pad)
 // If the flag says "not converged" (rare) the consumer simply runs again behind the next chunk.
 // edges != nullptr: the sweeps write the pixels they promote straight into that edge map (which must already
 // hold the strong pixels); there is then nothing left for a consumer to do.
+// One propagation in flight: a frame range with its planes, scheduling words, flags and the stream it runs on.
+struct PropLane {
+    hipStream_t stream = nullptr;
+    uint64_t *S = nullptr;
+    const uint64_t *C = nullptr;
+    unsigned *sched = nullptr, *flags = nullptr; // device: tile stamps + queues + counters; last_change, domain
+    unsigned *host = nullptr, *host_dev = nullptr; // 4 pinned words: last_change, domain, sequence number, spare
+    hipEvent_t event = nullptr;                    // recorded behind every publish (fallback wait, stream join)
+    HystGeom g{};
+    short *edges = nullptr;
+    int edge_value = 0;
+    int iter = 0;       // sweeps launched so far
+    unsigned seq = 0;   // sequence number of the last publish
+    bool converged = false;
+};
+
+constexpr int kSweepChunk = 8;
+constexpr int kMaxSweeps = 1 << 22;
+
+// Launches the next chunk of sweeps of a lane and, behind them, the one-thread kernel that publishes the two
+// flag words and a sequence number in pinned host memory (the host spins on the sequence number: ~5 us from the
+// last sweep to the host knowing, against ~35 us for an async copy plus an event wait).
+int lane_launch_chunk(canny_hip_ctx *ctx, PropLane &L)
+{
+    {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_PROPAGATE, L.stream);
+        for (int k = 0; k < kSweepChunk; k++)
+            HIP_TRY(ctx, launch_hyst_propagate(L.S, L.C, L.sched, L.flags, L.iter + k, L.g, L.stream, L.edges,
+                                               L.edge_value));
+    }
+    L.iter += kSweepChunk;
+    L.seq = ++ctx->publish_seq;
+    HIP_TRY(ctx, launch_hyst_publish(L.flags, L.host_dev, L.seq, L.stream));
+    HIP_TRY(ctx, hipEventRecord(L.event, L.stream));
+    return CANNY_HIP_OK;
+}
+
+// Waits for the chunk launched last and reads its verdict into L.converged.
+int lane_wait(canny_hip_ctx *ctx, PropLane &L)
+{
+    volatile unsigned *hf = L.host;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&hf[2], __ATOMIC_ACQUIRE) != L.seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            HIP_TRY(ctx, hipEventSynchronize(L.event)); // errors surface here
+            if (__atomic_load_n(&hf[2], __ATOMIC_ACQUIRE) != L.seq) return CANNY_HIP_ERR_RUNTIME;
+        }
+    }
+    if (hf[1]) return CANNY_HIP_ERR_DOMAIN;
+    L.converged = hf[0] != (unsigned)L.iter; // nothing was scheduled for sweep `iter`
+    if (!L.converged && L.iter >= kMaxSweeps) return CANNY_HIP_ERR_NO_CONVERGE;
+    if (L.converged) ctx->last_hyst_iters = std::max(ctx->last_hyst_iters, (int)hf[0] + 1);
+    return CANNY_HIP_OK;
+}
+
+// The whole frame range of a call as one lane on the context's stream.
+PropLane main_lane(canny_hip_ctx *ctx, const HystGeom &g, short *edges, int edge_value)
+{
+    PropLane L;
+    L.stream = ctx->stream;
+    L.S = (uint64_t *)ctx->plane_s.p;
+    L.C = (const uint64_t *)ctx->plane_c.p;
+    L.sched = (unsigned *)ctx->stamps.p;
+    L.flags = (unsigned *)ctx->flags.p;
+    L.host = ctx->host_flags;
+    L.host_dev = ctx->host_flags_dev;
+    L.event = ctx->flag_event;
+    L.g = g;
+    L.edges = edges;
+    L.edge_value = edge_value;
+    return L;
+}
+
 template <class Consumer>
 int run_propagation(canny_hip_ctx *ctx, const HystGeom &g, bool speculative, Consumer &&consumer,
                     short *edges = nullptr, int edge_value = 0)
 {
-    uint64_t *S = (uint64_t *)ctx->plane_s.p;
-    const uint64_t *C = (const uint64_t *)ctx->plane_c.p;
-    unsigned *stamp = (unsigned *)ctx->stamps.p; // tile stamps + work queues + queue counters
-    unsigned *flags = (unsigned *)ctx->flags.p;
-    const int kMaxSweeps = 1 << 22;
-    int iter = 0, rc;
-    for (;;) {
-        const int chunk = 8;
-        {
-            StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_PROPAGATE);
-            for (int k = 0; k < chunk; k++)
-                HIP_TRY(ctx, launch_hyst_propagate(S, C, stamp, flags, iter + k, g, ctx->stream, edges, edge_value));
-        }
-        iter += chunk;
-        // A one-thread kernel publishes the two flag words and a sequence number in pinned host memory and the
-        // host spins on the sequence number: ~5 us from the last sweep to the host knowing, against ~35 us for
-        // an async copy plus an event wait (copy-engine hand-over, interrupt, wake-up).
-        const unsigned seq = ++ctx->publish_seq;
-        HIP_TRY(ctx, launch_hyst_publish(flags, ctx->host_flags_dev, seq, ctx->stream));
-        HIP_TRY(ctx, hipEventRecord(ctx->flag_event, ctx->stream)); // fallback if the spin times out
+    PropLane L = main_lane(ctx, g, edges, edge_value);
+    ctx->last_hyst_iters = 0;
+    int rc;
+    do {
+        if ((rc = lane_launch_chunk(ctx, L))) return rc;
         if (speculative && (rc = consumer())) return rc;
-        {
-            volatile unsigned *hf = ctx->host_flags;
-            const auto t0 = std::chrono::steady_clock::now();
-            unsigned spins = 0;
-            while (__atomic_load_n(&hf[2], __ATOMIC_ACQUIRE) != seq) {
-                __builtin_ia32_pause();
-                if ((++spins & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-                    HIP_TRY(ctx, hipEventSynchronize(ctx->flag_event)); // errors surface here
-                    if (__atomic_load_n(&hf[2], __ATOMIC_ACQUIRE) != seq) return CANNY_HIP_ERR_RUNTIME;
-                }
-            }
-        }
-        if (ctx->host_flags[1]) return CANNY_HIP_ERR_DOMAIN;
-        if (ctx->host_flags[0] != (unsigned)iter) break; // nothing scheduled for sweep `iter`
-        if (iter >= kMaxSweeps) return CANNY_HIP_ERR_NO_CONVERGE;
-    }
-    ctx->last_hyst_iters = (int)ctx->host_flags[0] + 1;
+        if ((rc = lane_wait(ctx, L))) return rc;
+    } while (!L.converged);
     return speculative ? CANNY_HIP_OK : consumer();
 }
 
@@ -329,9 +391,53 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
         HystGeom g = make_hyst_geom(h, w, n);
         if ((rc = ensure_hyst(ctx, g))) return rc;
         uint64_t *S = (uint64_t *)ctx->plane_s.p, *C = (uint64_t *)ctx->plane_c.p;
-        if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc; // the kernel below writes in-image bytes only
         // reached pixels hold EDGE=255 and survive the reference's final `< max_val -> 0` sweep only if 255 >= max_val
         const int edge_value = 255 >= hi ? 255 : 0;
+        if (ctx->overlap_hysteresis && n >= 16) {
+            // Two halves.  The sweeps of half A run on a second stream while the main stream does Sobel+NMS of
+            // half B: the sweeps are bound by launch and tile-load latency and leave most of the chip idle, the
+            // Sobel+NMS kernel fills it.  Only half B's propagation remains exposed at the end of the call.
+            if ((rc = ensure_aux_stream(ctx))) return rc;
+            const int nA = n / 2, nB = n - nA;
+            const HystGeom gA = make_hyst_geom(h, w, nA), gB = make_hyst_geom(h, w, nB);
+            const size_t px_a = npx(h, w, nA);
+            HIP_TRY(ctx, launch_hyst_prepare(S, C, g, /*zero_pad=*/true, (unsigned *)ctx->stamps.p,
+                                             (unsigned *)ctx->flags.p, ctx->stream, /*n_lanes=*/2));
+            PropLane A = main_lane(ctx, gA, d_edges, edge_value), B = main_lane(ctx, gB, d_edges + px_a, edge_value);
+            A.stream = ctx->aux_stream;
+            A.event = ctx->aux_event;
+            B.S += gA.words();
+            B.C += gA.words();
+            B.sched += hyst_sched_words(gA);
+            B.flags += 2;
+            B.host += 4;
+            B.host_dev += 4;
+            {
+                StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+                HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, A.S, (uint64_t *)A.C, gA, lo, hi, edge_value,
+                                                             ctx->stream, ctx->tune_sobel_seg));
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
+            ctx->last_hyst_iters = 0;
+            if ((rc = lane_launch_chunk(ctx, A))) return rc;
+            {
+                StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+                HIP_TRY(ctx, launch_sobel_nms_classify_march(sm + px_a, d_edges + px_a, B.S, (uint64_t *)B.C, gB, lo, hi,
+                                                             edge_value, ctx->stream, ctx->tune_sobel_seg));
+            }
+            if ((rc = lane_launch_chunk(ctx, B))) return rc;
+            for (PropLane *L : {&A, &B}) {
+                if ((rc = lane_wait(ctx, *L))) return rc;
+                while (!L->converged) {
+                    if ((rc = lane_launch_chunk(ctx, *L)) || (rc = lane_wait(ctx, *L))) return rc;
+                }
+            }
+            // whatever the caller queues on the context's stream next must see half A's edge map complete
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, A.event, 0));
+            return CANNY_HIP_OK;
+        }
+        if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc; // the kernel below writes in-image bytes only
         {
             StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
             HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, S, C, g, lo, hi, edge_value, ctx->stream,
@@ -433,6 +539,9 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
     for (auto &b : ctx->io) b.release();
     if (ctx->host_flags) (void)hipHostFree(ctx->host_flags);
     if (ctx->flag_event) (void)hipEventDestroy(ctx->flag_event);
+    if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+    if (ctx->aux_event) (void)hipEventDestroy(ctx->aux_event);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     for (auto &v : ctx->pending)
         for (auto &e : v) {
             (void)hipEventDestroy(e.a);
@@ -462,6 +571,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "sobel_nms_path") && value <= 2) ctx->sobel_nms_path = value;
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
     else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
+    else if (!std::strcmp(name, "overlap_hysteresis") && value <= 1) ctx->overlap_hysteresis = value;
     else if (!std::strcmp(name, "tune_sobel_px") && value <= 1) sobel_nms_set_px_variant(value); // process-wide
     else if (!std::strcmp(name, "gaussian_fma_div") && value <= 1) gaussian_set_fma_div(value != 0); // process-wide
     else if (!std::strcmp(name, "tune_finalize_mode") && value <= 1) hyst_set_finalize_mode(value);   // process-wide

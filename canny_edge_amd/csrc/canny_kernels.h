@@ -96,8 +96,10 @@ inline size_t hyst_sched_words(const HystGeom &g) { return 3 * (size_t)g.tiles()
 // First launch of a hysteresis call: zeroes sched (hyst_sched_words(g) words) and flags[0..1] (last_change,
 // domain) and, if zero_pad, the plane bits outside the image (tile padding; needed when the planes are filled
 // by launch_sobel_nms_classify_march, which writes in-image bytes only; requires width % 8 == 0).
+// n_lanes > 1: the frames are propagated as n_lanes independent ranges (each with its own scheduling words, laid
+// out back to back -- 3 * tiles + 4 * n_lanes words in all -- and its own pair of flags: 2 * n_lanes words).
 hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom &g, bool zero_pad, unsigned *sched,
-                               unsigned *flags, hipStream_t stream);
+                               unsigned *flags, hipStream_t stream, int n_lanes = 1);
 // edges != nullptr: an edge map that already holds the initially strong pixels; each sweep writes edge_value
 // into the pixels it promotes, so the map is final when propagation has converged (no finalize pass).
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,

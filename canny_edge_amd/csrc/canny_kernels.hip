@@ -806,7 +806,8 @@ hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t 
 // of two memsets and a kernel: each of those costs ~10 us of launch gap on the stream).
 __global__ __launch_bounds__(256) void hyst_prepare_kernel(uint64_t *__restrict__ strong, uint64_t *__restrict__ conn,
                                                            HystGeom g, int pad_waves, unsigned *__restrict__ sched,
-                                                           unsigned n_sched, unsigned *__restrict__ flags)
+                                                           unsigned n_sched, unsigned *__restrict__ flags,
+                                                           int n_flags)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
@@ -831,19 +832,22 @@ __global__ __launch_bounds__(256) void hyst_prepare_kernel(uint64_t *__restrict_
     const size_t i0 = ((size_t)(wave - pad_waves) * 64 + lane) * 4;
     for (int j = 0; j < 4; j++)
         if (i0 + j < n_sched) sched[i0 + j] = 0u;
-    if (wave == pad_waves && lane == 0) flags[0] = flags[1] = 0u;
+    if (wave == pad_waves && lane < n_flags) flags[lane] = 0u;
 }
 
 hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom &g, bool zero_pad, unsigned *sched,
-                               unsigned *flags, hipStream_t stream)
+                               unsigned *flags, hipStream_t stream, int n_lanes)
 {
+    if (n_lanes < 1 || n_lanes > 16) return hipErrorInvalidValue;
     const bool pad = zero_pad && (g.height % kTile != 0 || g.width % kTile != 0);
     const long long pad_waves = pad ? (long long)(g.tiles_x + g.tiles_y) * g.n_frames : 0;
-    const size_t n_sched = hyst_sched_words(g);
+    // n_lanes independent propagations over disjoint frame ranges: their scheduling words lie back to back
+    // (3 words per tile + 4 per lane) and so do their flag pairs
+    const size_t n_sched = 3 * (size_t)g.tiles() + 4 * (size_t)n_lanes;
     const long long waves = pad_waves + (long long)((n_sched + 255) / 256);
     if (pad_waves > 0x3fffffffLL || n_sched > 0xffffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(hyst_prepare_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, strong, conn, g,
-                       (int)pad_waves, sched, (unsigned)n_sched, flags);
+                       (int)pad_waves, sched, (unsigned)n_sched, flags, 2 * n_lanes);
     return hipGetLastError();
 }
 

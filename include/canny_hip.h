@@ -94,6 +94,9 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "gaussian_fma_div": 1 (default) / 0 -- single-fma division by the full-window weight (process-wide)
  *   "fuse_classify": 1 (default) / 0 -- canny(): the Sobel+NMS kernel writes the hysteresis bit-planes itself
  *                    (used when width % 8 == 0 and min_val >= 1; otherwise the separate kernels run)
+ *   "overlap_hysteresis": 0 (default) / 1 -- canny() on 16 or more frames: the propagation sweeps of the first half
+ *                    of the batch run on a second stream beside the Sobel+NMS kernel of the second half
+ *                    (measured 1.5 % slower on 128 x 4K, kept for A/B)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
  *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide)
  *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel with the row-pass product table in LDS,

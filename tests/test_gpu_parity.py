@@ -534,3 +534,44 @@ def test_canny_unaligned_device_buffers(hip):
         finally:
             c.free(d_in)
             c.free(d_out)
+
+
+def _serpentine_image(h, w):
+    """A dim one-pixel-wide serpentine line with one bright end: after Sobel+NMS its flanks are weak edges that
+    hysteresis can only reach by walking the whole line from the bright (strong) end, tile after tile."""
+    img = np.zeros((h, w), np.uint8)
+    rows = list(range(4, h - 4, 8))
+    for k, r in enumerate(rows):
+        img[r, 4:w - 4] = 60
+        if k + 1 < len(rows):
+            c = w - 5 if k % 2 == 0 else 4
+            img[r:rows[k + 1] + 1, c] = 60
+    img[rows[0], 4:12] = 255
+    return img
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_canny_overlapped_halves(hip, overlap):
+    """canny() on >= 16 frames runs the two halves' propagations on two streams; frames 2 and 11 need far more
+    than one chunk of sweeps, so both lanes go through the relaunch loop."""
+    h, w, n = 200, 328, 16
+    frames = np.stack([_mixed(h, w, 70 + i) for i in range(n)])
+    frames[2] = _serpentine_image(h, w)
+    frames[11] = _serpentine_image(h, w)[::-1].copy()
+    want = np.stack([oracle.canny(f, 0.3, 50, 250) for f in frames])
+    assert np.count_nonzero(want[2]) > 2000  # the walk really happens
+    with hip.Context(0) as c:
+        c.set_option("overlap_hysteresis", overlap)
+        d_in, d_out = c.malloc(frames.nbytes), c.malloc(frames.nbytes * 2)
+        try:
+            c.h2d(d_in, frames)
+            for _ in range(2):  # twice: the second call reuses every workspace and event
+                c.dev_canny(d_in, 0.3, 50, 250, h, w, n, d_out)
+                got = np.empty(frames.shape, np.int16)
+                c.d2h(got, d_out)
+                bad = np.argwhere(got != want)
+                assert bad.size == 0, (overlap, bad[:5].tolist())
+            assert c.last_hysteresis_iterations > 8
+        finally:
+            c.free(d_in)
+            c.free(d_out)

@@ -17,11 +17,14 @@ import sys
 
 FRAMES, HEIGHT, WIDTH = 128, 2160, 3840  # bench.py's default workload (what tools/pmc_passes.sh runs)
 
-KERNELS = {  # key in the JSON -> (substring of the rocprofv3 kernel name, algorithmic bytes per pixel, note)
-    "sobel_nms_classify": ("sobel_nms_march_kernel<true, 4>", 4.25,
+# key in the JSON -> (substring of the rocprofv3 kernel name, algorithmic bytes per pixel, frames per launch, note)
+# canny() launches the fused kernel once per half of the batch; bench.py times the s16 kernel on the whole batch.
+KERNELS = {
+    "sobel_nms_classify": ("sobel_nms_march_kernel<true, 4>", 4.25, FRAMES // 2,
                            "16 B/lane reads (FETCH_SIZE doubled); 16 B/lane edge-map writes (exact) plus the plane "
                            "bytes (raw WRITE_SIZE, 6 % of the writes)"),
-    "sobel_nms": ("sobel_nms_march_kernel<false, 4>", 4.0, "16 B/lane reads (FETCH_SIZE doubled) and writes (exact)"),
+    "sobel_nms": ("sobel_nms_march_kernel<false, 4>", 4.0, FRAMES,
+                  "16 B/lane reads (FETCH_SIZE doubled) and writes (exact)"),
 }
 
 
@@ -39,9 +42,9 @@ def main():
     out = sys.argv[2] if len(sys.argv) > 2 else "profiles/traffic_sobel_nms.json"
     fetch = mean_per_dispatch(pmc_dir, "fetch", "FETCH_SIZE")
     write = mean_per_dispatch(pmc_dir, "write", "WRITE_SIZE")
-    px = FRAMES * HEIGHT * WIDTH
     kernels = {}
-    for key, (needle, bpp, note) in KERNELS.items():
+    for key, (needle, bpp, frames_per_launch, note) in KERNELS.items():
+        px = frames_per_launch * HEIGHT * WIDTH
         f = [(v, n) for k, (v, n) in fetch.items() if needle in k]
         w = [(v, n) for k, (v, n) in write.items() if needle in k]
         if not f or not w:
@@ -50,7 +53,7 @@ def main():
         write_b = w[0][0] * 1024.0
         alg = bpp * px
         kernels[key] = {
-            "kernel": needle, "dispatches_averaged": [f[0][1], w[0][1]],
+            "kernel": needle, "frames_per_launch": frames_per_launch, "dispatches_averaged": [f[0][1], w[0][1]],
             "fetch_size_kib_raw": round(f[0][0], 1), "write_size_kib_raw": round(w[0][0], 1),
             "fetch_bytes_corrected": int(fetch_b), "write_bytes": int(write_b),
             "hbm_bytes_per_launch": int(fetch_b + write_b),

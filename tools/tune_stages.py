@@ -138,9 +138,11 @@ def main():
     import time
     names = ["gaussian", "sobel_nms", "hyst_classify", "hyst_propagate", "hyst_finalize"]
     pipe = {}
+    modes = ((0, 0), (1, 0), (1, 1))  # (fuse_classify, overlap_hysteresis)
     for _ in range(args.rounds):
-        for fuse in (0, 1):
+        for fuse, overlap in modes:
             ctx.set_option("fuse_classify", fuse)
+            ctx.set_option("overlap_hysteresis", overlap)
             ctx.profile_reset()
             ctx.synchronize()
             t0 = time.perf_counter()
@@ -148,12 +150,14 @@ def main():
             ctx.synchronize()
             wall = (time.perf_counter() - t0) * 1e3
             row = [ctx.profile_get(sid)[0] for sid in range(5)]
-            pipe.setdefault(fuse, []).append(row + [wall])
+            pipe.setdefault((fuse, overlap), []).append(row + [wall])
     ctx.set_option("fuse_classify", 1)
-    for fuse in (0, 1):
-        med = [statistics.median(col) for col in zip(*pipe[fuse])]
+    ctx.set_option("overlap_hysteresis", 0)
+    for fuse, overlap in modes:
+        med = [statistics.median(col) for col in zip(*pipe[(fuse, overlap)])]
         parts = "  ".join(f"{n} {v:.3f}" for n, v in zip(names, med))
-        print(f"canny fuse_classify={fuse}: {parts}  | stages {sum(med[:5]):.3f} ms, wall {med[5]:.3f} ms")
+        print(f"canny fuse_classify={fuse} overlap_hysteresis={overlap}: {parts}  | stages {sum(med[:5]):.3f} ms, "
+              f"wall {med[5]:.3f} ms")
     ctx.close()
 
 

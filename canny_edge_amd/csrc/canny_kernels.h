@@ -74,6 +74,8 @@ hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, i
 // Fused Sobel+NMS, wave-marching and LDS-free (canny_sobel_nms_march.hip); smoothed must lie in [0,255].
 bool sobel_nms_march_supported(int height, int width);
 void sobel_nms_set_px_variant(int v); // A/B: 0 = 8 pixels per lane, 1 = 4 pixels per lane (more resident waves)
+// A/B (fused kernel): 0 = plane bytes staged in LDS for 8 rows and written as 8-byte words, 1 = direct byte stores
+void sobel_nms_set_plane_store_variant(int v);
 hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
                                   hipStream_t stream, int tune_seg = 0);
 

@@ -115,8 +115,8 @@ struct StripJob {
 // the classify pass (2 B/px of loads) and the finalize pass (2 B/px of stores in an HBM-bound kernel) both
 // disappear from the pipeline; this kernel pays about +0.1 ms per 64 4K frames for its three stores per row
 // (they do not hide behind the VALU work: see DESIGN.md, "store latency").
-template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP>
-__device__ __forceinline__ void march_strip(const StripJob &jb)
+template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP, bool LDS_PLANES>
+__device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_mem)
 {
     constexpr int PX = 2 * NP;
     const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend;
@@ -169,6 +169,57 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
 #pragma unroll
         for (int e = 0; e < PX; e++) cP[a][e] = cQ[a][e] = 0.0f;
     }
+
+    // ---- plane bytes through LDS (interior strips of the 8-pixel PLANES kernel) -----------------------------
+    // A lane's plane byte belongs to a 64-bit plane word shared with seven other lanes, and consecutive rows of
+    // a tile are consecutive words: stored directly, every row costs two byte-store instructions that hit eight
+    // or nine tiles.  Instead the wave keeps eight rows of its 62 bytes per plane in LDS (row pitch 72 bytes =
+    // nine words, byte column = position in the first word + lane) and then writes them out with one 8-byte store
+    // per (row, full word) and one 2-byte store per leftover pair: four store instructions per eight rows instead
+    // of sixteen.  LDS instructions do not count in vmcnt, which is what the row loop stalls on.
+    constexpr bool STAGE = LDS_PLANES && PLANES && NP == 4 && !COL_EDGE;
+    constexpr unsigned kStagePitch = 72, kStagePlane = 8 * kStagePitch;
+    uint8_t *const stage = stage_mem;
+    unsigned stage_col = 0, fw_lds = 0, fw_gl = 0, pc_lds = 0, pc_gl = 0;
+    int fw_j = 99, pc_j = 99; // 99 = this lane has no such role
+    if (STAGE) {
+        const int strip_b0 = (x0 - (jb.lane - 1) * PX) >> 3; // byte column of lane 1 (wave-uniform, even)
+        const int o = strip_b0 & 7, w0 = strip_b0 >> 3;      // position in its plane word, tile column of that word
+        stage_col = jb.lane == 0 ? 71u : (unsigned)(o + jb.lane - 1); // lane 0 and 63 (halo) land in unread bytes
+        // seven of the strip's words are complete: 0..6 if it starts on a word boundary, else 1..7
+        if ((jb.lane & 7) < 7) {
+            const int wfull = (jb.lane & 7) + (o ? 1 : 0);
+            fw_j = jb.lane >> 3;
+            fw_lds = (unsigned)fw_j * kStagePitch + (unsigned)wfull * 8u;
+            fw_gl = (unsigned)(w0 + wfull) * 512u + (unsigned)fw_j * 8u;
+        }
+        // the other 6 bytes are three byte pairs at the strip's ends (o is even): lanes 0..23, three per row
+        if (jb.lane < 24) {
+            const int p = jb.lane % 3, n_first = ((8 - o) >> 1) & 3;
+            const int i = p < n_first ? o + 2 * p : 8 * ((o + 62) >> 3) + 2 * (p - n_first);
+            pc_j = jb.lane / 3;
+            pc_lds = (unsigned)pc_j * kStagePitch + (unsigned)i;
+            pc_gl = (unsigned)(w0 + (i >> 3)) * 512u + (unsigned)pc_j * 8u + (unsigned)(i & 7);
+        }
+    }
+    auto stage_flush = [&](int y2) { // y2 = last row staged: rows (y2 & ~7) .. y2 go out
+        const int jmax = y2 & 7;
+        const unsigned gbase = (unsigned)(y2 >> 6) * (unsigned)jb.tiles_x * 512u + (unsigned)((y2 & 63) & ~7) * 8u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // compiler: the byte writes above come first
+        if (fw_j <= jmax) {
+            const uint64_t wc = *reinterpret_cast<const uint64_t *>(stage + fw_lds);
+            const uint64_t ws = *reinterpret_cast<const uint64_t *>(stage + kStagePlane + fw_lds);
+            *reinterpret_cast<uint64_t *>(jb.pconn + gbase + fw_gl) = wc;
+            *reinterpret_cast<uint64_t *>(jb.pstrong + gbase + fw_gl) = ws;
+        }
+        if (pc_j <= jmax) {
+            const uint16_t hc = *reinterpret_cast<const uint16_t *>(stage + pc_lds);
+            const uint16_t hs = *reinterpret_cast<const uint16_t *>(stage + kStagePlane + pc_lds);
+            *reinterpret_cast<uint16_t *>(jb.pconn + gbase + pc_gl) = hc;
+            *reinterpret_cast<uint16_t *>(jb.pstrong + gbase + pc_gl) = hs;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // ... and the next group's writes come after
+    };
 
     // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
     auto step = [&](auto ph, int r, const uint32_t (&p)[NP]) {
@@ -290,7 +341,14 @@ __device__ __forceinline__ void march_strip(const StripJob &jb)
                     cbits |= from_right(cbits) << 4;
                     sb |= from_right(sb) << 4;
                 }
-                if (owner) { // W % 8 == 0: an owner lane's pixels are all inside the image
+                if (STAGE) {
+                    // plane bytes: staged in LDS for eight rows, then written as whole 8-byte words (see stage_flush)
+                    const unsigned rowoff = (unsigned)(y2 & 7) * kStagePitch;
+                    stage[rowoff + stage_col] = (uint8_t)cbits; // halo lanes write pad columns nobody reads
+                    stage[kStagePlane + rowoff + stage_col] = (uint8_t)sb;
+                    if ((y2 & 7) == 7 || y2 == yend - 1) stage_flush(y2);
+                    if (owner) __builtin_memcpy(jb.fout + (size_t)y2 * W + x0, outp, 4 * NP);
+                } else if (owner) { // W % 8 == 0: an owner lane's pixels are all inside the image
                     if (NP == 4 || (jb.lane & 1)) {
                         const unsigned bx = (unsigned)x0 >> 3;
                         const unsigned off = ((unsigned)(y2 >> 6) * (unsigned)jb.tiles_x + (bx >> 3)) * 512u +
@@ -338,7 +396,7 @@ struct PlaneArgs { // PLANES instantiation only
     int tiles_x, tiles_y, lo1, hi1, edge_value;
 };
 
-template <bool PLANES, int NP>
+template <bool PLANES, int NP, bool LDS_PLANES>
 __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int16_t *__restrict__ in,
                                                                        int16_t *__restrict__ out, int H, int W,
                                                                        int n_strips, int n_segs, int seg_rows,
@@ -346,6 +404,9 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
 {
     // readfirstlane tells the compiler what it cannot prove: everything derived from the wave index is
     // wave-uniform, so rows, segments and border tests live in SGPRs and branch with s_cbranch.
+    // per-wave staging area of the plane bytes (LDS_PLANES kernels only): 2 planes x 8 rows x 72 bytes
+    __shared__ __attribute__((aligned(8))) uint8_t stage_lds[LDS_PLANES ? SNM_WPB * 2 * 8 * 72 : 8];
+    uint8_t *stage_mem = stage_lds + (LDS_PLANES ? (threadIdx.x >> 6) * (2 * 8 * 72) : 0);
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * SNM_WPB + (threadIdx.x >> 6));
     if (wave >= total_waves) return;
     const int s = wave % n_strips;
@@ -375,14 +436,14 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
     const bool row_edge = (jb.ybeg < 2) || (jb.yend + 5 >= H);
     if (col_edge) {
         if (row_edge)
-            march_strip<true, true, PLANES, NP>(jb);
+            march_strip<true, true, PLANES, NP, LDS_PLANES>(jb, stage_mem);
         else
-            march_strip<true, false, PLANES, NP>(jb);
+            march_strip<true, false, PLANES, NP, LDS_PLANES>(jb, stage_mem);
     } else {
         if (row_edge)
-            march_strip<false, true, PLANES, NP>(jb);
+            march_strip<false, true, PLANES, NP, LDS_PLANES>(jb, stage_mem);
         else
-            march_strip<false, false, PLANES, NP>(jb);
+            march_strip<false, false, PLANES, NP, LDS_PLANES>(jb, stage_mem);
     }
 }
 
@@ -390,6 +451,9 @@ bool sobel_nms_march_supported(int height, int width) { return height >= 2 && wi
 
 static int px_variant = 0; // A/B switch "tune_sobel_px": 0 = 8 pixels per lane, 1 = 4 pixels per lane
 void sobel_nms_set_px_variant(int v) { px_variant = v; }
+// A/B switch "tune_plane_stores": 0 = plane bytes staged in LDS and written as words, 1 = direct byte stores
+static int plane_store_variant = 0;
+void sobel_nms_set_plane_store_variant(int v) { plane_store_variant = v; }
 
 // tune_seg: 0 = automatic, else rows per segment (A/B knob).
 static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const PlaneArgs *planes, int height, int width,
@@ -409,18 +473,21 @@ static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const Plan
     unsigned blocks = (unsigned)((waves + SNM_WPB - 1) / SNM_WPB);
     const PlaneArgs pl = planes ? *planes : PlaneArgs{};
     const dim3 grid(blocks), block(SNM_WPB * 64);
-    if (planes && np == 4)
-        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 4>), grid, block, 0, stream, smoothed, out, height, width,
-                           n_strips, n_segs, seg, (int)waves, pl);
+    if (planes && np == 4 && plane_store_variant == 0)
+        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 4, true>), grid, block, 0, stream, smoothed, out, height,
+                           width, n_strips, n_segs, seg, (int)waves, pl);
+    else if (planes && np == 4)
+        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 4, false>), grid, block, 0, stream, smoothed, out, height,
+                           width, n_strips, n_segs, seg, (int)waves, pl);
     else if (planes)
-        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 2>), grid, block, 0, stream, smoothed, out, height, width,
-                           n_strips, n_segs, seg, (int)waves, pl);
+        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 2, false>), grid, block, 0, stream, smoothed, out, height,
+                           width, n_strips, n_segs, seg, (int)waves, pl);
     else if (np == 4)
-        hipLaunchKernelGGL((sobel_nms_march_kernel<false, 4>), grid, block, 0, stream, smoothed, out, height, width,
-                           n_strips, n_segs, seg, (int)waves, pl);
+        hipLaunchKernelGGL((sobel_nms_march_kernel<false, 4, false>), grid, block, 0, stream, smoothed, out, height,
+                           width, n_strips, n_segs, seg, (int)waves, pl);
     else
-        hipLaunchKernelGGL((sobel_nms_march_kernel<false, 2>), grid, block, 0, stream, smoothed, out, height, width,
-                           n_strips, n_segs, seg, (int)waves, pl);
+        hipLaunchKernelGGL((sobel_nms_march_kernel<false, 2, false>), grid, block, 0, stream, smoothed, out, height,
+                           width, n_strips, n_segs, seg, (int)waves, pl);
     return hipGetLastError();
 }
 

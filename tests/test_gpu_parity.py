@@ -435,14 +435,18 @@ def test_gaussian_half_windows_covered():
     assert centers == list(range(1, 9)), centers
 
 
-@pytest.fixture(params=[0, 1], ids=["8px_per_lane", "4px_per_lane"])
+@pytest.fixture(params=[(0, 0), (1, 0), (0, 1)], ids=["8px_per_lane", "4px_per_lane", "8px_direct_plane_stores"])
 def sobel_px(hip, request):
-    """Runs a test once per variant of the marching Sobel+NMS kernel (process-wide A/B switch)."""
+    """Runs a test once per variant of the marching Sobel+NMS kernel (process-wide A/B switches): pixels per
+    lane, and whether the fused kernel stages its plane bytes in LDS (default) or stores them directly."""
+    px, direct = request.param
     with hip.Context(0) as c:
-        c.set_option("tune_sobel_px", request.param)
+        c.set_option("tune_sobel_px", px)
+        c.set_option("tune_plane_stores", direct)
     yield request.param
     with hip.Context(0) as c:
         c.set_option("tune_sobel_px", 0)
+        c.set_option("tune_plane_stores", 0)
 
 
 @pytest.mark.parametrize("path", [1, 2])

@@ -76,6 +76,20 @@ def main():
     for (kind, px), v in sorted(pres.items()):
         print(f"Sobel+NMS {kind:5s} {'4' if px else '8'} px/lane: median {statistics.median(v):.4f} ms  min {min(v):.4f} ms")
 
+    # fused kernel: plane bytes staged in LDS (default) vs stored directly
+    sres = {0: [], 1: []}
+    for _ in range(args.rounds):
+        for direct in (0, 1):
+            ctx.set_option("tune_plane_stores", direct)
+            ctx.profile_reset()
+            ctx.dev_canny(d_img, args.sigma, 50, 150, H, W, F, d_out)
+            ctx.synchronize()
+            sres[direct].append(ctx.profile_get(capi.STAGE_SOBEL_NMS)[0])
+    ctx.set_option("tune_plane_stores", 0)
+    for direct in (0, 1):
+        print(f"Sobel+NMS fused, plane bytes {'stored directly' if direct else 'staged in LDS  '}: median "
+              f"{statistics.median(sres[direct]):.4f} ms  min {min(sres[direct]):.4f} ms")
+
     gmodes = [(variant, fma) for variant in (0, 2, 1) for fma in (0, 1)]
     gres = {m: [] for m in gmodes}
     for _ in range(args.rounds):

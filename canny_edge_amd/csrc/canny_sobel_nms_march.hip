@@ -177,29 +177,50 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
     // nine words, byte column = position in the first word + lane) and then writes them out with one 8-byte store
     // per (row, full word) and one 2-byte store per leftover pair: four store instructions per eight rows instead
     // of sixteen.  LDS instructions do not count in vmcnt, which is what the row loop stalls on.
-    constexpr bool STAGE = LDS_PLANES && PLANES && NP == 4 && !COL_EDGE;
+    // Border strips (COL_EDGE) own fewer than 62 bytes in the last strip and possibly an odd number: their
+    // leftovers are written byte by byte, one instruction for the first partial word and one for the last.
+    constexpr bool STAGE = LDS_PLANES && PLANES && NP == 4;
     constexpr unsigned kStagePitch = 72, kStagePlane = 8 * kStagePitch;
     uint8_t *const stage = stage_mem;
-    unsigned stage_col = 0, fw_lds = 0, fw_gl = 0, pc_lds = 0, pc_gl = 0;
-    int fw_j = 99, pc_j = 99; // 99 = this lane has no such role
+    unsigned stage_col = 0, fw_lds = 0, fw_gl = 0, pc_lds = 0, pc_gl = 0, pl_lds = 0, pl_gl = 0;
+    int fw_j = 99, pc_j = 99, pl_j = 99; // row of the group this lane writes in each role; 99 = no such role
     if (STAGE) {
         const int strip_b0 = (x0 - (jb.lane - 1) * PX) >> 3; // byte column of lane 1 (wave-uniform, even)
         const int o = strip_b0 & 7, w0 = strip_b0 >> 3;      // position in its plane word, tile column of that word
-        stage_col = jb.lane == 0 ? 71u : (unsigned)(o + jb.lane - 1); // lane 0 and 63 (halo) land in unread bytes
-        // seven of the strip's words are complete: 0..6 if it starts on a word boundary, else 1..7
-        if ((jb.lane & 7) < 7) {
-            const int wfull = (jb.lane & 7) + (o ? 1 : 0);
-            fw_j = jb.lane >> 3;
-            fw_lds = (unsigned)fw_j * kStagePitch + (unsigned)wfull * 8u;
-            fw_gl = (unsigned)(w0 + wfull) * 512u + (unsigned)fw_j * 8u;
+        const int nb = COL_EDGE ? max(0, min(62, (W >> 3) - strip_b0)) : 62; // bytes owned (lanes 1..nb)
+        const int e = o + nb;                                 // owned byte columns of a staged row: [o, e)
+        stage_col = jb.lane == 0 ? 71u : (unsigned)(o + jb.lane - 1); // non-owner lanes land in bytes nobody reads
+        const int j = jb.lane >> 3, q = jb.lane & 7;
+        // complete words: from the first word boundary at or after o up to e
+        const int wfull = q + (o ? 1 : 0);
+        if (q < 7 && 8 * wfull + 8 <= e) {
+            fw_j = j;
+            fw_lds = (unsigned)j * kStagePitch + (unsigned)wfull * 8u;
+            fw_gl = (unsigned)(w0 + wfull) * 512u + (unsigned)j * 8u;
         }
-        // the other 6 bytes are three byte pairs at the strip's ends (o is even): lanes 0..23, three per row
-        if (jb.lane < 24) {
-            const int p = jb.lane % 3, n_first = ((8 - o) >> 1) & 3;
-            const int i = p < n_first ? o + 2 * p : 8 * ((o + 62) >> 3) + 2 * (p - n_first);
-            pc_j = jb.lane / 3;
-            pc_lds = (unsigned)pc_j * kStagePitch + (unsigned)i;
-            pc_gl = (unsigned)(w0 + (i >> 3)) * 512u + (unsigned)pc_j * 8u + (unsigned)(i & 7);
+        if (!COL_EDGE) {
+            // interior strip: the other 6 bytes are three byte pairs at the strip's ends (o is even): lanes 0..23
+            if (jb.lane < 24) {
+                const int p = jb.lane % 3, n_first = ((8 - o) >> 1) & 3;
+                const int i = p < n_first ? o + 2 * p : 8 * (e >> 3) + 2 * (p - n_first);
+                pc_j = jb.lane / 3;
+                pc_lds = (unsigned)pc_j * kStagePitch + (unsigned)i;
+                pc_gl = (unsigned)(w0 + (i >> 3)) * 512u + (unsigned)pc_j * 8u + (unsigned)(i & 7);
+            }
+        } else {
+            // first partial word: bytes [o, min(8, e)) when o > 0; last partial word: bytes [8*wl, e) when it is
+            // not complete and not the first word again (or when the strip starts on a word boundary)
+            const int wl = e >> 3;
+            if (o > 0 && q >= o && q < min(8, e)) {
+                pc_j = j;
+                pc_lds = (unsigned)j * kStagePitch + (unsigned)q;
+                pc_gl = (unsigned)w0 * 512u + (unsigned)j * 8u + (unsigned)q;
+            }
+            if ((wl > 0 || o == 0) && q < (e & 7)) {
+                pl_j = j;
+                pl_lds = (unsigned)j * kStagePitch + (unsigned)(8 * wl + q);
+                pl_gl = (unsigned)(w0 + wl) * 512u + (unsigned)j * 8u + (unsigned)q;
+            }
         }
     }
     auto stage_flush = [&](int y2) { // y2 = last row staged: rows (y2 & ~7) .. y2 go out
@@ -212,11 +233,22 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
             *reinterpret_cast<uint64_t *>(jb.pconn + gbase + fw_gl) = wc;
             *reinterpret_cast<uint64_t *>(jb.pstrong + gbase + fw_gl) = ws;
         }
-        if (pc_j <= jmax) {
-            const uint16_t hc = *reinterpret_cast<const uint16_t *>(stage + pc_lds);
-            const uint16_t hs = *reinterpret_cast<const uint16_t *>(stage + kStagePlane + pc_lds);
-            *reinterpret_cast<uint16_t *>(jb.pconn + gbase + pc_gl) = hc;
-            *reinterpret_cast<uint16_t *>(jb.pstrong + gbase + pc_gl) = hs;
+        if (!COL_EDGE) {
+            if (pc_j <= jmax) {
+                const uint16_t hc = *reinterpret_cast<const uint16_t *>(stage + pc_lds);
+                const uint16_t hs = *reinterpret_cast<const uint16_t *>(stage + kStagePlane + pc_lds);
+                *reinterpret_cast<uint16_t *>(jb.pconn + gbase + pc_gl) = hc;
+                *reinterpret_cast<uint16_t *>(jb.pstrong + gbase + pc_gl) = hs;
+            }
+        } else {
+            if (pc_j <= jmax) {
+                jb.pconn[gbase + pc_gl] = stage[pc_lds];
+                jb.pstrong[gbase + pc_gl] = stage[kStagePlane + pc_lds];
+            }
+            if (pl_j <= jmax) {
+                jb.pconn[gbase + pl_gl] = stage[pl_lds];
+                jb.pstrong[gbase + pl_gl] = stage[kStagePlane + pl_lds];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // ... and the next group's writes come after
     };

@@ -20,10 +20,10 @@ FRAMES, HEIGHT, WIDTH = 128, 2160, 3840  # bench.py's default workload (what too
 # key in the JSON -> (substring of the rocprofv3 kernel name, algorithmic bytes per pixel, frames per launch, note)
 # (with the option overlap_hysteresis=1 canny() would launch the fused kernel once per half of the batch)
 KERNELS = {
-    "sobel_nms_classify": ("sobel_nms_march_kernel<true, 4>", 4.25, FRAMES,
+    "sobel_nms_classify": ("sobel_nms_march_kernel<true, 4,", 4.25, FRAMES,
                            "16 B/lane reads (FETCH_SIZE doubled); 16 B/lane edge-map writes (exact) plus the plane "
                            "bytes (raw WRITE_SIZE, 6 % of the writes)"),
-    "sobel_nms": ("sobel_nms_march_kernel<false, 4>", 4.0, FRAMES,
+    "sobel_nms": ("sobel_nms_march_kernel<false, 4,", 4.0, FRAMES,
                   "16 B/lane reads (FETCH_SIZE doubled) and writes (exact)"),
 }
 

@@ -1,4 +1,5 @@
-// canny_sobel_nms_march.hip -- fused Sobel + non-maximal suppression, wave-marching, LDS-free.
+// canny_sobel_nms_march.hip -- fused Sobel + non-maximal suppression, wave-marching; the stencils use no LDS
+// (the variant canny() runs stages its hysteresis plane bytes there on their way out).
 //
 // The roofline-graded pass: s16 smoothed plane in, s16 suppressed magnitude out, 4 algorithmic bytes
 // per pixel; gradient, magnitude and angle never leave registers.
@@ -113,8 +114,8 @@ struct StripJob {
 // W % 8 == 0 (a lane's 8 pixels are one plane byte).  The s16 plane it writes is not the suppressed magnitude
 // but the provisional EDGE MAP (strong -> edge value, else 0), which the propagation sweeps complete in place:
 // the classify pass (2 B/px of loads) and the finalize pass (2 B/px of stores in an HBM-bound kernel) both
-// disappear from the pipeline; this kernel pays about +0.1 ms per 64 4K frames for its three stores per row
-// (they do not hide behind the VALU work: see DESIGN.md, "store latency").
+// disappear from the pipeline.  Stores are what this kernel's row loop stalls on ("store latency"),
+// so the plane bytes do not go out row by row: see LDS_PLANES below.
 template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP, bool LDS_PLANES>
 __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_mem)
 {

@@ -53,6 +53,9 @@ def parse():
                     help="frames the CPU baseline times (rank 0, N=1): ~0.37 s each, i.e. ~12 s by default")
     ap.add_argument("--fuse-classify", type=int, default=1, choices=(0, 1),
                     help="0: canny() runs Sobel+NMS and the hysteresis classify pass as separate kernels (A/B)")
+    ap.add_argument("--stream", type=int, default=0, choices=(0, 1),
+                    help="1: steps go through canny_hip_dev_canny_stream (the sweeps of step i finish beside the "
+                         "Gaussian of step i+1, two alternating output buffers); 0: plain canny_hip_dev_canny calls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the pre-timing parity spot check")
     return ap.parse_args()
@@ -110,6 +113,7 @@ def main():
     idx = torch.arange(F, device=dev) % distinct
     d_img = base[idx].contiguous()                       # [F, H, W] uint8, resident in HBM
     d_edges = torch.empty((F, H, W), dtype=torch.int16, device=dev)
+    d_edges_b = torch.empty((F, H, W), dtype=torch.int16, device=dev) if args.stream else None
     del base
     torch.cuda.synchronize()
 
@@ -118,15 +122,31 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option("fuse_classify", args.fuse_classify)
 
-    def step():
+    def plain_step():
         ctx.dev_canny(d_img.data_ptr(), args.sigma, args.min_val, args.max_val, H, W, F, d_edges.data_ptr())
+
+    calls = [0]
+
+    def stream_step():
+        # a stream of batches: the edge map of call i is complete once call i+1 (or the flush) has returned, so
+        # consecutive calls write alternating buffers as a consumer of the maps would need them to
+        out = d_edges if calls[0] % 2 == 0 else d_edges_b
+        calls[0] += 1
+        ctx.dev_canny_stream(d_img.data_ptr(), args.sigma, args.min_val, args.max_val, H, W, F, out.data_ptr())
+
+    step = stream_step if args.stream else plain_step
+
+    def drain():
+        if args.stream:
+            ctx.dev_canny_stream_flush()
+        torch.cuda.synchronize()
 
     # parity spot check (outside the timed region): frame 0 of this rank against the oracle
     parity = None
     if not args.no_check and rank == 0:
         import oracle
         step()
-        torch.cuda.synchronize()
+        drain()
         got = d_edges[0].cpu().numpy()
         want = oracle.canny(base_np[0], args.sigma, args.min_val, args.max_val)
         parity = bool(np.array_equal(got, want))
@@ -135,7 +155,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    drain()
+    # Inside the timed region only the roofline kernel's stage carries HIP events (one pair per step): every pair
+    # costs a few microseconds of stream time, and with all stages bracketed a step ran ~0.08 ms (3 %) longer.
+    # The other stages are timed in a second, untimed pass of the same K steps right after.
+    ctx.set_option("profile_stage_mask", 1 << capi.STAGE_SOBEL_NMS)
     ctx.profile_enable(True)
     ctx.profile_reset()
 
@@ -145,21 +169,49 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    drain()  # the last step's sweeps are inside the timed region
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
         elapsed = sharding.max_over_ranks(elapsed, dev)
 
+    sn_ms_total, sn_launches = ctx.profile_get(capi.STAGE_SOBEL_NMS)
+    ctx.set_option("profile_stage_mask", 0)  # all stages
+    ctx.profile_reset()
+    for _ in range(args.steps):
+        step()
+    drain()
     stages = {}
     for sid, name in enumerate(capi.STAGE_NAMES[:5]):
         ms, n = ctx.profile_get(sid)
-        stages[name] = {"ms_per_step": round(ms / max(1, args.steps), 4), "launch_groups": n}
+        stages[name] = {"ms_per_step": round(ms / max(1, args.steps), 4), "launch_groups": n,
+                        "timed": "second pass, all stages bracketed by events"}
+    stages["sobel_nms"] = {"ms_per_step": round(sn_ms_total / max(1, args.steps), 4), "launch_groups": sn_launches,
+                           "timed": "inside the timed region"}
     ctx.profile_enable(False)
     hyst_sweeps = ctx.last_hysteresis_iterations
 
     px_per_step = F * H * W
     value = sharding.aggregate_throughput(px_per_step * args.steps, world, elapsed) / 1e6
+
+    # the same steps as plain blocking calls (each returns with its edge map complete), for comparison
+    plain = None
+    if args.stream:
+        plain_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            plain_step()
+        torch.cuda.synchronize()
+        el_plain = time.perf_counter() - t1
+        if world > 1:
+            dist.barrier()
+            el_plain = sharding.max_over_ranks(el_plain, dev)
+        plain = {"value": round(sharding.aggregate_throughput(px_per_step * args.steps, world, el_plain) / 1e6, 1),
+                 "unit": "Mpixels/s", "ms_per_step": round(el_plain / args.steps * 1e3, 4),
+                 "what": "same workload through canny_hip_dev_canny (no overlap between consecutive steps)"}
 
     # ---- roofline -------------------------------------------------------------------------------------
     # PMC-measured HBM bytes per launch (profiles/traffic_sobel_nms.json, made by tools/pmc_passes.sh +
@@ -245,11 +297,15 @@ def main():
         "config": {"workload": f"{F}x {W}x{H} gray frames per GPU per step, sigma={args.sigma}, "
                                f"thresholds {args.min_val}/{args.max_val}, inputs resident in HBM",
                    "frames_per_gpu": F, "height": H, "width": W, "sigma": args.sigma,
+                   "calls": ("canny_hip_dev_canny_stream: hysteresis sweeps of step i overlap the Gaussian of step "
+                             "i+1; all K steps complete inside the timed region") if args.stream
+                   else "canny_hip_dev_canny (blocking)",
                    "sharding": "independent frames per GPU, no collective"},
         "roofline": roofline,
         "roofline_sobel_nms_s16": roofline_s16,
         "roofline_other_kernels": per_kernel,
         "stages": stages,
+        "plain_calls": plain,
         "hysteresis_sweeps": hyst_sweeps,
         "parity_checked": parity,
     }

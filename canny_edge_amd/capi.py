@@ -40,7 +40,7 @@ EXPORTS = (
     "canny_hip_hysteresis", "canny_hip_find_edge_pixels", "canny_hip_canny", "canny_hip_canny_batch",
     "canny_hip_canny_batch_u8", "canny_hip_dev_canny_u8", "canny_hip_canny_multi_gpu", "canny_hip_shard_range", "canny_hip_dev_gaussian", "canny_hip_dev_xy_gradient",
     "canny_hip_dev_sobel", "canny_hip_dev_nms", "canny_hip_dev_sobel_nms", "canny_hip_dev_hysteresis",
-    "canny_hip_dev_canny", "canny_hip_profile_enable", "canny_hip_profile_reset", "canny_hip_profile_get",
+    "canny_hip_dev_canny", "canny_hip_dev_canny_stream", "canny_hip_dev_canny_stream_flush", "canny_hip_profile_enable", "canny_hip_profile_reset", "canny_hip_profile_get",
     "canny_hip_selftest_mag_angle", "canny_hip_selftest_div", "canny_hip_selftest_div_fma",
     "canny_hip_selftest_div_fma_table",
 )
@@ -106,6 +106,8 @@ def load() -> C.CDLL:
         "canny_hip_dev_sobel_nms": ([p, p, i, i, i, p], i),
         "canny_hip_dev_hysteresis": ([p, p, i, i, i, i, i], i),
         "canny_hip_dev_canny": ([p, p, f, i, i, i, i, i, p], i),
+        "canny_hip_dev_canny_stream": ([p, p, f, i, i, i, i, i, p], i),
+        "canny_hip_dev_canny_stream_flush": ([p], i),
         "canny_hip_profile_enable": ([p, i], i),
         "canny_hip_profile_reset": ([p], i),
         "canny_hip_profile_get": ([p, i, C.POINTER(C.c_double), C.POINTER(C.c_long)], i),
@@ -374,6 +376,16 @@ class Context:
     def dev_canny(self, d_img: int, sigma: float, min_val: int, max_val: int, h: int, w: int, n: int, d_edges: int):
         self._check(self._L.canny_hip_dev_canny(self._h, C.c_void_p(d_img), sigma, min_val, max_val, h, w, n,
                                                 C.c_void_p(d_edges)), "dev_canny")
+
+    def dev_canny_stream(self, d_img: int, sigma: float, min_val: int, max_val: int, h: int, w: int, n: int,
+                         d_edges: int):
+        """canny() for a stream of batches: returns with this batch's hysteresis sweeps in flight; d_edges is
+        complete once the next dev_canny_stream call or dev_canny_stream_flush() has returned."""
+        self._check(self._L.canny_hip_dev_canny_stream(self._h, C.c_void_p(d_img), sigma, min_val, max_val, h, w, n,
+                                                       C.c_void_p(d_edges)), "dev_canny_stream")
+
+    def dev_canny_stream_flush(self):
+        self._check(self._L.canny_hip_dev_canny_stream_flush(self._h), "dev_canny_stream_flush")
 
     def dev_canny_u8(self, d_img: int, sigma: float, min_val: int, max_val: int, h: int, w: int, n: int, d_edges: int):
         self._check(self._L.canny_hip_dev_canny_u8(self._h, C.c_void_p(d_img), sigma, min_val, max_val, h, w, n,

@@ -60,6 +60,22 @@ struct EventPair {
     hipEvent_t a, b;
 };
 
+// One propagation in flight: a frame range with its planes, scheduling words, flags and the stream it runs on.
+struct PropLane {
+    hipStream_t stream = nullptr;
+    uint64_t *S = nullptr;
+    const uint64_t *C = nullptr;
+    unsigned *sched = nullptr, *flags = nullptr; // device: tile stamps + queues + counters; last_change, domain
+    unsigned *host = nullptr, *host_dev = nullptr; // 4 pinned words: last_change, domain, sequence number, spare
+    hipEvent_t event = nullptr;                    // recorded behind every publish (fallback wait, stream join)
+    HystGeom g{};
+    short *edges = nullptr;
+    int edge_value = 0;
+    int iter = 0;       // sweeps launched so far
+    unsigned seq = 0;   // sequence number of the last publish
+    bool converged = false;
+};
+
 } // namespace
 
 struct canny_hip_ctx {
@@ -90,9 +106,13 @@ struct canny_hip_ctx {
     int overlap_hysteresis = 0;
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_event = nullptr, aux_event = nullptr;
+    // canny_hip_dev_canny_stream: the propagation of the batch submitted last, still in flight on aux_stream
+    PropLane pend;
+    bool has_pend = false;
 
     // profiling
     bool prof = false;
+    unsigned prof_mask = ~0u; // stages whose launches get an event pair (each pair costs a few us of stream time)
     std::vector<EventPair> pending[CANNY_HIP_STAGE_COUNT];
     std::vector<EventPair> pool;
     double total_ms[CANNY_HIP_STAGE_COUNT] = {0};
@@ -133,7 +153,7 @@ struct StageTimer {
     StageTimer(canny_hip_ctx *c, int s, hipStream_t on_stream = nullptr)
         : ctx(c), stage(s), stream(on_stream ? on_stream : c->stream)
     {
-        if (!ctx->prof) return;
+        if (!ctx->prof || !(ctx->prof_mask >> s & 1u)) return;
         if (!ctx->pool.empty()) {
             ev = ctx->pool.back();
             ctx->pool.pop_back();
@@ -226,7 +246,12 @@ int ensure_hyst(canny_hip_ctx *ctx, const HystGeom &g)
 
 int ensure_aux_stream(canny_hip_ctx *ctx)
 {
-    if (!ctx->aux_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->aux_stream) {
+        // highest priority: what runs here is short and latency bound, and the main stream's kernels fill the chip
+        int least = 0, greatest = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, greatest));
+    }
     if (!ctx->fork_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
     if (!ctx->aux_event) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming));
     return CANNY_HIP_OK;
@@ -250,22 +275,6 @@ int prepare_hyst(canny_hip_ctx *ctx, const HystGeom &g, bool zero_pad)
 // If the flag says "not converged" (rare) the consumer simply runs again behind the next chunk.
 // edges != nullptr: the sweeps write the pixels they promote straight into that edge map (which must already
 // hold the strong pixels); there is then nothing left for a consumer to do.
-// One propagation in flight: a frame range with its planes, scheduling words, flags and the stream it runs on.
-struct PropLane {
-    hipStream_t stream = nullptr;
-    uint64_t *S = nullptr;
-    const uint64_t *C = nullptr;
-    unsigned *sched = nullptr, *flags = nullptr; // device: tile stamps + queues + counters; last_change, domain
-    unsigned *host = nullptr, *host_dev = nullptr; // 4 pinned words: last_change, domain, sequence number, spare
-    hipEvent_t event = nullptr;                    // recorded behind every publish (fallback wait, stream join)
-    HystGeom g{};
-    short *edges = nullptr;
-    int edge_value = 0;
-    int iter = 0;       // sweeps launched so far
-    unsigned seq = 0;   // sequence number of the last publish
-    bool converged = false;
-};
-
 constexpr int kSweepChunk = 8;
 constexpr int kMaxSweeps = 1 << 22;
 
@@ -352,11 +361,13 @@ int propagate_and_finalize(canny_hip_ctx *ctx, const HystGeom &g, short *d_out, 
     });
 }
 
+int finish_pending(canny_hip_ctx *ctx);
+
 int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int lo, int hi)
 {
     HystGeom g = make_hyst_geom(h, w, n);
-    int rc = ensure_hyst(ctx, g);
-    if (rc) return rc;
+    int rc = finish_pending(ctx); // a streamed call's sweeps own the planes until they are done
+    if (rc || (rc = ensure_hyst(ctx, g))) return rc;
     if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/false))) return rc; // the classify kernels write whole tiles
     {
         StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_CLASSIFY);
@@ -381,10 +392,11 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
               short *d_edges)
 {
     if (h < 2 || w < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    int rc = finish_pending(ctx);
+    if (rc) return rc;
     HIP_TRY(ctx, ctx->smoothed.ensure(npx(h, w, n) * sizeof(short)));
     short *sm = (short *)ctx->smoothed.p;
-    int rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm);
-    if (rc) return rc;
+    if ((rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm))) return rc;
     if (ctx->fuse_classify && ctx->sobel_nms_path != 1 && sobel_nms_classify_supported(h, w, lo)) {
         // Sobel+NMS writes the hysteresis bit-planes directly: the suppressed magnitudes never reach memory
         // and the classify pass disappears (canny() does not return them; the stage API still does).
@@ -448,6 +460,63 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
     }
     if ((rc = dev_sobel_nms(ctx, sm, h, w, n, d_edges))) return rc;
     return dev_hysteresis(ctx, d_edges, h, w, n, lo, hi);
+}
+
+// Completes the propagation canny_hip_dev_canny_stream left in flight and joins it into the context's stream.
+int finish_pending(canny_hip_ctx *ctx)
+{
+    if (!ctx->has_pend) return CANNY_HIP_OK;
+    ctx->has_pend = false; // also on errors: the lane is not resumable
+    PropLane &L = ctx->pend;
+    int rc;
+    if ((rc = lane_wait(ctx, L))) return rc;
+    while (!L.converged)
+        if ((rc = lane_launch_chunk(ctx, L)) || (rc = lane_wait(ctx, L))) return rc;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, L.event, 0));
+    return CANNY_HIP_OK;
+}
+
+// canny() for a stream of batches (the reference's capture loop, src/main.cpp:120-137, with batches for frames).
+// The sweeps of hysteresis are bound by launch and tile-load latency and leave most of the chip idle; here they
+// run on a second stream and the call returns with them in flight, so that the next call's Gaussian (VALU bound,
+// touches none of the hysteresis state) fills the chip beside them.  Per call:
+//   main stream:  Gaussian(i) ......... | wait P(i-1) | prepare, Sobel+NMS+classify(i) |
+//   aux stream:   P(i-1) sweeps ....... |                                              | P(i) sweeps ...
+//   host:         enqueue G(i); spin on P(i-1)'s flag (more chunks if needed); enqueue the rest; return
+// The bit-planes, scheduling words and the smoothed plane stay single-buffered: everything that writes them is
+// ordered behind P(i-1) by the event join, and the Gaussian writes only the smoothed plane, which Sobel+NMS(i-1)
+// has finished reading (same stream).
+int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int lo, int hi, int h, int w, int n,
+                     short *d_edges)
+{
+    if (h < 2 || w < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    if (!(ctx->fuse_classify && ctx->sobel_nms_path != 1 && sobel_nms_classify_supported(h, w, lo))) {
+        int rc = finish_pending(ctx); // shapes the fused kernel does not take: plain call, nothing left in flight
+        return rc ? rc : dev_canny(ctx, d_img, sigma, lo, hi, h, w, n, d_edges);
+    }
+    HIP_TRY(ctx, ctx->smoothed.ensure(npx(h, w, n) * sizeof(short)));
+    short *sm = (short *)ctx->smoothed.p;
+    int rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm);
+    if (rc) return rc;
+    if ((rc = finish_pending(ctx))) return rc; // host waits here while the Gaussian runs
+    HystGeom g = make_hyst_geom(h, w, n);
+    if ((rc = ensure_hyst(ctx, g)) || (rc = ensure_aux_stream(ctx))) return rc;
+    const int edge_value = 255 >= hi ? 255 : 0;
+    if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc;
+    {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+        HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, (uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p,
+                                                     g, lo, hi, edge_value, ctx->stream, ctx->tune_sobel_seg));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
+    ctx->pend = main_lane(ctx, g, d_edges, edge_value);
+    ctx->pend.stream = ctx->aux_stream;
+    ctx->pend.event = ctx->aux_event;
+    ctx->last_hyst_iters = 0;
+    if ((rc = lane_launch_chunk(ctx, ctx->pend))) return rc;
+    ctx->has_pend = true;
+    return CANNY_HIP_OK;
 }
 
 int h2d(canny_hip_ctx *ctx, DevBuf &b, const void *src, size_t bytes)
@@ -528,6 +597,8 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)finish_pending(ctx);
+    if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->tmp_f32.release();
     ctx->smoothed.release();
@@ -557,7 +628,8 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
 
 int canny_hip_ctx_set_stream(canny_hip_ctx *ctx, void *hip_stream)
 {
-    if (!ctx) return CANNY_HIP_ERR_INVALID;
+    int rc = bind(ctx);
+    if (rc || (rc = finish_pending(ctx))) return rc; // joins the old stream
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return CANNY_HIP_OK;
 }
@@ -572,6 +644,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
     else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
     else if (!std::strcmp(name, "overlap_hysteresis") && value <= 1) ctx->overlap_hysteresis = value;
+    else if (!std::strcmp(name, "profile_stage_mask")) ctx->prof_mask = value ? (unsigned)value : ~0u;
     else if (!std::strcmp(name, "tune_sobel_px") && value <= 1) sobel_nms_set_px_variant(value); // process-wide
     else if (!std::strcmp(name, "tune_plane_stores") && value <= 1) sobel_nms_set_plane_store_variant(value); // process-wide
     else if (!std::strcmp(name, "gaussian_fma_div") && value <= 1) gaussian_set_fma_div(value != 0); // process-wide
@@ -585,7 +658,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
 int canny_hip_synchronize(canny_hip_ctx *ctx)
 {
     int rc = bind(ctx);
-    if (rc) return rc;
+    if (rc || (rc = finish_pending(ctx))) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CANNY_HIP_OK;
 }
@@ -1030,6 +1103,22 @@ int canny_hip_dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float si
     if (!d_img || !d_edges) return CANNY_HIP_ERR_INVALID;
     if ((rc = check_dims(height, width, n_frames))) return rc;
     return dev_canny(ctx, d_img, sigma, min_val, max_val, height, width, n_frames, d_edges);
+}
+
+int canny_hip_dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
+                               int height, int width, int n_frames, short *d_edges)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_img || !d_edges) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    return dev_canny_stream(ctx, d_img, sigma, min_val, max_val, height, width, n_frames, d_edges);
+}
+
+int canny_hip_dev_canny_stream_flush(canny_hip_ctx *ctx)
+{
+    int rc = bind(ctx);
+    return rc ? rc : finish_pending(ctx);
 }
 
 int canny_hip_dev_canny_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,

@@ -104,7 +104,10 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel with the row-pass product table in LDS,
  *                    1 LDS-ring marching kernel, 2 symmetric-tap kernel that multiplies (process-wide)
  *   "tune_gaussian_seg": approximate rows per wave segment of the marching Gaussian, 0 = automatic (process-wide)
- *   "tune_finalize_mode": 0 (default) row-major hysteresis finalize, 1 tile-patch finalize (process-wide) */
+ *   "tune_finalize_mode": 0 (default) row-major hysteresis finalize, 1 tile-patch finalize (process-wide)
+ *   "profile_stage_mask": bit s set = stage s (CANNY_HIP_STAGE_*) gets an event pair while profiling is enabled;
+ *                    0 (default) = all stages.  Every pair costs a few microseconds of stream time, so a timed
+ *                    region that needs one kernel's duration enables that stage only. */
 int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value);
 int canny_hip_synchronize(canny_hip_ctx *ctx);
 /* Text of the last HIP runtime error seen by this context ("" if none). */
@@ -177,6 +180,19 @@ int canny_hip_dev_hysteresis(canny_hip_ctx *ctx, short *d_edge_candidates, int h
 /* gaussian -> fused sobel+nms -> hysteresis over n_frames resident frames. */
 int canny_hip_dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
                         int height, int width, int n_frames, short *d_edges);
+/* canny() for a STREAM of batches -- the reference's capture loop (src/main.cpp:120-137: canny() on one frame
+ * after the other) with resident batches in place of frames.  Same results as canny_hip_dev_canny, but the call
+ * returns with the batch's hysteresis sweeps still in flight on a second stream of the context; they finish
+ * beside the next call's Gaussian (the sweeps are latency bound, the Gaussian is VALU bound).  d_edges of call i
+ * is complete -- for work queued on the context's stream and, after a synchronize, for the host -- once call i+1
+ * or canny_hip_dev_canny_stream_flush() has returned; until then the caller must neither read nor free it.
+ * d_img may be reused as soon as the context's stream has passed the call.  Every other compute entry point of
+ * the context, ctx_set_stream, synchronize and destroy flush first, so mixing the two kinds of call is safe
+ * (canny_hip_memcpy_* do not flush: copying batch i-1 out while batch i is in flight is the point).  Shapes the fused Sobel+NMS+classify kernel
+ * does not take (width % 8 != 0, min_val < 1) run as a plain canny_hip_dev_canny. */
+int canny_hip_dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
+                               int height, int width, int n_frames, short *d_edges);
+int canny_hip_dev_canny_stream_flush(canny_hip_ctx *ctx);
 /* Same with an 8-bit edge map (0 / 255) as output; the s16 map is kept in a context workspace and narrowed
  * by one more elementwise kernel (this entry point exists for transfers, not for speed on the device). */
 int canny_hip_dev_canny_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,

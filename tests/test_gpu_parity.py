@@ -579,3 +579,65 @@ def test_canny_overlapped_halves(hip, overlap):
         finally:
             c.free(d_in)
             c.free(d_out)
+
+
+def test_canny_stream_of_batches(hip):
+    """canny_hip_dev_canny_stream leaves each batch's sweeps in flight beside the next batch's Gaussian.  Batches
+    of different content (one of them needs several chunks of sweeps), separate and reused output buffers, a
+    plain call in between, a shape the fused kernel does not take, and flush / synchronize as the last word."""
+    h, w, n = 200, 328, 6
+    batches = []
+    for b in range(4):
+        frames = np.stack([_mixed(h, w, 300 + 10 * b + i) for i in range(n)])
+        if b == 1:
+            frames[3] = _serpentine_image(h, w)
+        batches.append(frames)
+    want = [np.stack([oracle.canny(f, 0.3, 50, 250) for f in fr]) for fr in batches]
+    odd = np.stack([_mixed(h, w - 3, 900 + i) for i in range(2)])
+    want_odd = np.stack([oracle.canny(f, 0.3, 50, 250) for f in odd])
+    with hip.Context(0) as c:
+        nbytes = batches[0].nbytes
+        d_in = [c.malloc(nbytes) for _ in range(2)]
+        d_out = [c.malloc(nbytes * 2) for _ in range(4)]
+        d_odd_in, d_odd_out = c.malloc(odd.nbytes), c.malloc(odd.nbytes * 2)
+        try:
+            def fetch(ptr, shape=batches[0].shape):
+                got = np.empty(shape, np.int16)
+                c.d2h(got, ptr)
+                return got
+
+            # 1) four batches back to back into four buffers (inputs double-buffered), then flush
+            for b in range(4):
+                c.h2d(d_in[b % 2], batches[b])
+                c.dev_canny_stream(d_in[b % 2], 0.3, 50, 250, h, w, n, d_out[b])
+                if b:  # the previous batch is complete as soon as this call has returned
+                    assert np.array_equal(fetch(d_out[b - 1]), want[b - 1]), b - 1
+            c.dev_canny_stream_flush()
+            assert np.array_equal(fetch(d_out[3]), want[3])
+            c.dev_canny_stream_flush()  # nothing pending: no-op
+
+            # 2) one output buffer reused by every call; synchronize() finishes the last one
+            for rnd in range(2):
+                for b in (1, 2, 0):
+                    c.h2d(d_in[0], batches[b])
+                    c.dev_canny_stream(d_in[0], 0.3, 50, 250, h, w, n, d_out[0])
+                c.synchronize()
+                assert np.array_equal(fetch(d_out[0]), want[0]), rnd
+
+            # 3) a plain call (and the stage API) while a streamed batch is in flight
+            c.h2d(d_in[0], batches[1])
+            c.h2d(d_in[1], batches[2])
+            c.dev_canny_stream(d_in[0], 0.3, 50, 250, h, w, n, d_out[1])
+            c.dev_canny(d_in[1], 0.3, 50, 250, h, w, n, d_out[2])
+            assert np.array_equal(fetch(d_out[1]), want[1])
+            assert np.array_equal(fetch(d_out[2]), want[2])
+
+            # 4) a width the fused kernel does not take runs as a plain call, with a streamed batch before it
+            c.dev_canny_stream(d_in[0], 0.3, 50, 250, h, w, n, d_out[3])
+            c.h2d(d_odd_in, odd)
+            c.dev_canny_stream(d_odd_in, 0.3, 50, 250, h, w - 3, 2, d_odd_out)
+            assert np.array_equal(fetch(d_odd_out, odd.shape), want_odd)
+            assert np.array_equal(fetch(d_out[3]), want[1])
+        finally:
+            for p in d_in + d_out + [d_odd_in, d_odd_out]:
+                c.free(p)

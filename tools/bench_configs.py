@@ -48,6 +48,24 @@ def main():
         ctx.synchronize()
     t_dev = timed(dev_once, 20)
     t_host = timed(lambda: ctx.canny(img, 1.4, 50, 150), 5)
+
+    # a stream of single frames (the reference's capture loop), blocking calls vs canny_hip_dev_canny_stream
+    d_out2 = ctx.malloc(img.nbytes * 2)
+    outs = (d_out, d_out2)
+
+    def loop(streamed, reps=200):
+        for i in range(reps):
+            if streamed:
+                ctx.dev_canny_stream(d_in, 1.4, 50, 150, H, W, 1, outs[i % 2])
+            else:
+                ctx.dev_canny(d_in, 1.4, 50, 150, H, W, 1, outs[i % 2])
+        ctx.synchronize()
+    t_loop = {s: timed(lambda: loop(s), 3) / 200 for s in (False, True)}
+    ctx.free(d_out2)
+    out["C2_stream_of_single_4k_frames"] = {
+        "blocking_calls_ms_per_frame": round(t_loop[False] * 1e3, 4),
+        "dev_canny_stream_ms_per_frame": round(t_loop[True] * 1e3, 4),
+        "dev_canny_stream_Mpix_s": round(H * W / t_loop[True] / 1e6, 1)}
     out["C2_single_4k_sigma1.4"] = {
         "device_resident_ms": round(t_dev * 1e3, 4), "device_resident_Mpix_s": round(H * W / t_dev / 1e6, 1),
         "host_to_host_ms": round(t_host * 1e3, 3), "host_to_host_Mpix_s": round(H * W / t_host / 1e6, 1),

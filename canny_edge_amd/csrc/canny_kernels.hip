@@ -414,6 +414,21 @@ __device__ __forceinline__ uint64_t row_below_u64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Row flood: every run of ones in p that contains a bit of g (g is a subset of p) becomes selected entirely.
+// The carry chain of an adder does the walk: adding a seed to its run of ones ripples upward to the run's end,
+// so the bits that p + g flips inside p are exactly [lowest seed of the run .. end of the run] minus the other
+// seeds (which are in g anyway); the carry stops in the zero above the run, so runs do not disturb each other,
+// and a carry out of bit 63 is simply lost.  The downward direction is the same on bit-reversed words.
+// ~20 32-bit instructions against ~100 (24 of them 64-bit shifts) for the two Kogge-Stone ladders this replaces:
+// sweep 0 floods 170 k tiles per 128-frame batch and is bound by exactly this arithmetic.
+__device__ __forceinline__ uint64_t fill_runs(uint64_t p, uint64_t g)
+{
+    const uint64_t up = ((p + g) ^ p) & p;
+    const uint64_t pr = __brevll(p), gr = __brevll(g);
+    const uint64_t down = __brevll(((pr + gr) ^ pr) & pr);
+    return g | up | down;
+}
+
 // Scheduling words of one hysteresis call (all zero before sweep 0):
 //   stamp[tiles]    sweep at which a tile was last queued (dedupes pushes within a sweep)
 //   queue[2][tiles] tiles to run in sweep k are queue[k & 1][0 .. count[k % 3])
@@ -434,33 +449,50 @@ __device__ __forceinline__ HystSched make_sched(unsigned *words, int tiles)
 
 // edges (may be null): edge map that already holds the initially strong pixels (written by the kernel that
 // filled the planes); every pixel this sweep promotes is written there at once, so no finalize pass is needed.
-__device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__restrict__ strong,
-                                               const uint64_t *__restrict__ conn, const HystSched &sch,
-                                               unsigned *__restrict__ last_change, int iter, const HystGeom &g,
-                                               int16_t *__restrict__ edges, int edge_value, uint64_t c)
+// A tile's own strong words and what it sees of its eight neighbours, as loaded (nothing here waits for memory).
+struct TileIn {
+    uint64_t s0, su, sd;          // own word; bottom row of the tile above; top row of the tile below
+    unsigned lb, rb;              // this row's column 63 of the left tile / column 0 of the right tile
+    unsigned ul, ur, dl, dr;      // the four corner pixels
+};
+
+__device__ __forceinline__ TileIn load_tile(int t, int lane, const uint64_t *__restrict__ strong, const HystGeom &g)
 {
-    // c = this lane's word of the tile's connectable plane, loaded by the caller.  Only connectable pixels can
-    // ever be added, so a tile without a single one (flat regions: most tiles of a natural frame) cannot
-    // change: leave before the strong plane and the nine halo loads are touched.
-    if (!__any(c != 0)) return;
     const int tpf = g.tiles_x * g.tiles_y;
     const int tt = t % tpf;
     const int ty = tt / g.tiles_x, tx = tt - ty * g.tiles_x;
     const bool hasU = ty > 0, hasD = ty < g.tiles_y - 1, hasL = tx > 0, hasR = tx < g.tiles_x - 1;
     const size_t base = (size_t)t * kTile;
     const size_t rowstep = (size_t)g.tiles_x * kTile; // words between vertically adjacent tiles
-
-    const uint64_t s0 = strong[base + lane];
+    TileIn in;
+    in.s0 = strong[base + lane];
     // halo from the eight neighbouring tiles (read once per sweep; a change made there during
     // this sweep re-stamps us for the next one)
-    const uint64_t su = hasU ? strong[base - rowstep + 63] : 0; // bottom row of the tile above
-    const uint64_t sd = hasD ? strong[base + rowstep] : 0;      // top row of the tile below
-    unsigned lb = hasL ? (unsigned)(strong[base - kTile + lane] >> 63) : 0u; // column 63 of the left tile
-    unsigned rb = hasR ? (unsigned)(strong[base + kTile + lane] & 1u) : 0u;  // column 0 of the right tile
-    const unsigned ul = (hasU && hasL) ? (unsigned)(strong[base - rowstep - kTile + 63] >> 63) : 0u;
-    const unsigned ur = (hasU && hasR) ? (unsigned)(strong[base - rowstep + kTile + 63] & 1u) : 0u;
-    const unsigned dl = (hasD && hasL) ? (unsigned)(strong[base + rowstep - kTile] >> 63) : 0u;
-    const unsigned dr = (hasD && hasR) ? (unsigned)(strong[base + rowstep + kTile] & 1u) : 0u;
+    in.su = hasU ? strong[base - rowstep + 63] : 0;
+    in.sd = hasD ? strong[base + rowstep] : 0;
+    in.lb = hasL ? (unsigned)(strong[base - kTile + lane] >> 63) : 0u;
+    in.rb = hasR ? (unsigned)(strong[base + kTile + lane] & 1u) : 0u;
+    in.ul = (hasU && hasL) ? (unsigned)(strong[base - rowstep - kTile + 63] >> 63) : 0u;
+    in.ur = (hasU && hasR) ? (unsigned)(strong[base - rowstep + kTile + 63] & 1u) : 0u;
+    in.dl = (hasD && hasL) ? (unsigned)(strong[base + rowstep - kTile] >> 63) : 0u;
+    in.dr = (hasD && hasR) ? (unsigned)(strong[base + rowstep + kTile] & 1u) : 0u;
+    return in;
+}
+
+// c = this lane's word of the tile's connectable plane (the caller has checked that the tile has any), in = the
+// tile as load_tile() returned it.
+__device__ __forceinline__ void process_tile(int t, int lane, uint64_t *__restrict__ strong, const HystSched &sch,
+                                             unsigned *__restrict__ last_change, int iter, const HystGeom &g,
+                                             int16_t *__restrict__ edges, int edge_value, uint64_t c,
+                                             const TileIn &in)
+{
+    const int tpf = g.tiles_x * g.tiles_y;
+    const int tt = t % tpf;
+    const int ty = tt / g.tiles_x, tx = tt - ty * g.tiles_x;
+    const bool hasU = ty > 0, hasD = ty < g.tiles_y - 1, hasL = tx > 0, hasR = tx < g.tiles_x - 1;
+    const size_t base = (size_t)t * kTile;
+    const uint64_t s0 = in.s0, su = in.su, sd = in.sd;
+    const unsigned lb = in.lb, rb = in.rb, ul = in.ul, ur = in.ur, dl = in.dl, dr = in.dr;
     unsigned lb_up = __shfl_up(lb, 1), lb_dn = __shfl_down(lb, 1);
     unsigned rb_up = __shfl_up(rb, 1), rb_dn = __shfl_down(rb, 1);
     if (lane == 0) { lb_up = ul; rb_up = ur; }
@@ -471,11 +503,6 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
     const bool quirk = (ty == 0 && tx == 0 && lane == 0);
 
     uint64_t s = s0;
-    // closed: s is already closed under the row flood below (it is the result of an earlier flood: every tile
-    // is flooded in sweep 0).  Then a round that adds no pixel from the 8-neighbourhood cannot change anything
-    // and the flood -- two thirds of a round's instructions -- is skipped; every tile's last round is such a one.
-    // (Sweep times did not move: the sweeps are bound by the latency of the tile loads, not by these instructions.)
-    bool closed = iter > 0;
     for (;;) {
         uint64_t up = row_above_u64(s), dn = row_below_u64(s);
         if (lane == 0) up = su;
@@ -484,26 +511,13 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
         uint64_t d_from_left = quirk ? (up | s | (dn & ~1ull)) : d; // what column c may pull from column c-1
         uint64_t nb = d | (d_from_left << 1) | (d >> 1) | in_left | in_right;
         uint64_t gsel = s | (c & nb);
-        if (closed && !__any(gsel != s)) break;
-        closed = true;
-        // flood along the row through runs of connectable pixels (Kogge-Stone, both directions)
-        uint64_t p = c;
-        gsel |= p & (gsel << 1);  p &= p << 1;
-        gsel |= p & (gsel << 2);  p &= p << 2;
-        gsel |= p & (gsel << 4);  p &= p << 4;
-        gsel |= p & (gsel << 8);  p &= p << 8;
-        gsel |= p & (gsel << 16); p &= p << 16;
-        gsel |= p & (gsel << 32);
-        p = c;
-        gsel |= p & (gsel >> 1);  p &= p >> 1;
-        gsel |= p & (gsel >> 2);  p &= p >> 2;
-        gsel |= p & (gsel >> 4);  p &= p >> 4;
-        gsel |= p & (gsel >> 8);  p &= p >> 8;
-        gsel |= p & (gsel >> 16); p &= p >> 16;
-        gsel |= p & (gsel >> 32);
-        bool changed = gsel != s;
-        s = gsel;
-        if (!__any(changed)) break;
+        // Nothing to add from the 8-neighbourhood: done.  (The row flood below only adds connectable pixels that
+        // are horizontal neighbours of selected ones, i.e. a subset of what a later round's `nb` would add, so it
+        // cannot find anything either; every tile's last round ends here, and so does the only round of the two
+        // thirds of sweep 0's tiles that have no weak pixel next to a strong one.)
+        if (!__any(gsel != s)) break;
+        // flood along the row through runs of connectable pixels, both directions
+        s = fill_runs(c, gsel);
     }
 
     const uint64_t chg = s ^ s0;
@@ -544,6 +558,19 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
             if (marked) atomicMax(last_change, nxt);
         }
     }
+}
+
+__device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__restrict__ strong,
+                                               const uint64_t *__restrict__ conn, const HystSched &sch,
+                                               unsigned *__restrict__ last_change, int iter, const HystGeom &g,
+                                               int16_t *__restrict__ edges, int edge_value, uint64_t c)
+{
+    // c = this lane's word of the tile's connectable plane, loaded by the caller.  Only connectable pixels can
+    // ever be added, so a tile without a single one (flat regions: most tiles of a natural frame) cannot
+    // change: leave before the strong plane and the nine halo loads are touched.
+    if (!__any(c != 0)) return;
+    const TileIn in = load_tile(t, lane, strong, g);
+    process_tile(t, lane, strong, sch, last_change, iter, g, edges, edge_value, c, in);
 }
 
 // Sweep 0 visits every tile (grid = tiles/4 workgroups); later sweeps are launched with a small fixed

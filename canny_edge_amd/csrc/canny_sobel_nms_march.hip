@@ -116,6 +116,15 @@ struct StripJob {
 // the classify pass (2 B/px of loads) and the finalize pass (2 B/px of stores in an HBM-bound kernel) both
 // disappear from the pipeline.  Stores are what this kernel's row loop stalls on ("store latency"),
 // so the plane bytes do not go out row by row: see LDS_PLANES below.
+// max(a, b, c) with a wave-uniform c in one instruction (the compiler turns max(max(a, b), c) into
+// max(max(a, c), max(b, c)) with the clamped magnitudes shared between pixels: one more v_max per pixel)
+__device__ __forceinline__ int max3_uniform(int a, int b, int c)
+{
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+
 template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP, bool LDS_PLANES>
 __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_mem)
 {
@@ -337,7 +346,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                 const int c = e + 1;
                 const int mc = M[m1][c];
                 // PLANES: min_val - 1 rides along as the third operand of a v_max3_i32 -- no extra instruction
-                auto nmax = [&](int a, int b) { return PLANES ? max(max(a, b), jb.lo1) : max(a, b); };
+                auto nmax = [&](int a, int b) { return PLANES ? max3_uniform(a, b, jb.lo1) : max(a, b); };
                 const int n0 = nmax(M[m1][c - 1], M[m1][c + 1]);
                 const int n90 = nmax(M[m0][c], M[m2][c]);
                 const int n45 = nmax(M[m0][c + 1], M[m2][c - 1]);  // up-right, down-left

@@ -53,9 +53,14 @@ def parse():
                     help="frames the CPU baseline times (rank 0, N=1): ~0.37 s each, i.e. ~12 s by default")
     ap.add_argument("--fuse-classify", type=int, default=1, choices=(0, 1),
                     help="0: canny() runs Sobel+NMS and the hysteresis classify pass as separate kernels (A/B)")
-    ap.add_argument("--stream", type=int, default=0, choices=(0, 1),
-                    help="1: steps go through canny_hip_dev_canny_stream (the sweeps of step i finish beside the "
-                         "Gaussian of step i+1, two alternating output buffers); 0: plain canny_hip_dev_canny calls")
+    ap.add_argument("--stream", type=int, default=0, choices=(0, 1, 2),
+                    help="1: steps go through canny_hip_dev_canny_stream (the host learns about step i's convergence "
+                         "after it has queued the Gaussian of step i+1; two alternating output buffers); 2: the same "
+                         "with the sweeps on a second stream beside that Gaussian; 0: plain canny_hip_dev_canny calls")
+    ap.add_argument("--spinup-seconds", type=float, default=0.6,
+                    help="untimed steps run for this long before the W warm-up steps: the device reaches its steady "
+                         "clocks only after a few tenths of a second of load (3 warm-up steps = 7 ms: 2.46 ms per "
+                         "step; 200: 2.40)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the pre-timing parity spot check")
     return ap.parse_args()
@@ -121,6 +126,7 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option("fuse_classify", args.fuse_classify)
+    ctx.set_option("stream_overlap", 1 if args.stream == 2 else 0)
 
     def plain_step():
         ctx.dev_canny(d_img.data_ptr(), args.sigma, args.min_val, args.max_val, H, W, F, d_edges.data_ptr())
@@ -153,13 +159,23 @@ def main():
         if not parity:
             raise SystemExit("bench.py: HIP edge map differs from the oracle -- refusing to report a number")
 
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup_seconds:  # clock spin-up, untimed (see --spinup-seconds)
+        for _ in range(8):
+            step()
+        drain()
     for _ in range(args.warmup):
         step()
     drain()
-    # Inside the timed region only the roofline kernel's stage carries HIP events (one pair per step): every pair
-    # costs a few microseconds of stream time, and with all stages bracketed a step ran ~0.08 ms (3 %) longer.
-    # The other stages are timed in a second, untimed pass of the same K steps right after.
+    # Inside the timed region only the roofline kernel carries HIP events, and that pair is ATTACHED to the kernel's
+    # dispatch (hipExtLaunchKernel start/stop events: the kernel's own begin/end timestamps) rather than recorded
+    # before and after it: a recorded pair puts two barrier packets into the stream and cost ~0.03-0.06 ms per step,
+    # with all stages bracketed ~0.08 ms (3 %).  The other stages are timed in a second, untimed pass of the same K
+    # steps right after.
+    # ... and only every 4th step carries that pair: even an attached pair makes the dispatch wait for the stream to
+    # drain (~0.04 ms per step it is on); `launches_timed` says how many launches the average is over.
     ctx.set_option("profile_stage_mask", 1 << capi.STAGE_SOBEL_NMS)
+    ctx.set_option("profile_sample_interval", max(1, min(4, args.steps // 3)))
     ctx.profile_enable(True)
     ctx.profile_reset()
 
@@ -177,6 +193,7 @@ def main():
 
     sn_ms_total, sn_launches = ctx.profile_get(capi.STAGE_SOBEL_NMS)
     ctx.set_option("profile_stage_mask", 0)  # all stages
+    ctx.set_option("profile_sample_interval", 1)
     ctx.profile_reset()
     for _ in range(args.steps):
         step()
@@ -186,8 +203,8 @@ def main():
         ms, n = ctx.profile_get(sid)
         stages[name] = {"ms_per_step": round(ms / max(1, args.steps), 4), "launch_groups": n,
                         "timed": "second pass, all stages bracketed by events"}
-    stages["sobel_nms"] = {"ms_per_step": round(sn_ms_total / max(1, args.steps), 4), "launch_groups": sn_launches,
-                           "timed": "inside the timed region"}
+    stages["sobel_nms"] = {"ms_per_step": round(sn_ms_total / max(1, sn_launches), 4), "launch_groups": sn_launches,
+                           "timed": "inside the timed region, on every 4th step"}
     ctx.profile_enable(False)
     hyst_sweeps = ctx.last_hysteresis_iterations
 
@@ -226,25 +243,25 @@ def main():
         except Exception:
             measured = {}
 
-    def roof(kernel, what, bytes_per_px, ms, launches, extra=None):
-        """ms = device time of this kernel per step, launches = how often it was launched in all timed steps
-        (canny() launches the Sobel+NMS kernel once per half of the batch)."""
-        per_step = max(1, round(launches / max(1, args.steps)))
+    def roof(kernel, what, bytes_per_px, total_ms, launches, extra=None):
+        """total_ms = summed device time of the `launches` launches of this kernel that carried events; every
+        launch covers the whole batch of F frames (one launch per step)."""
+        avg = total_ms / launches if launches else 0.0
         alg = bytes_per_px * px_per_step
-        ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        ach = alg / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
         m = measured.get(kernel, {})
-        traffic = m.get("hbm_bytes_per_launch") if m.get("frames_per_launch") == F // per_step else None
+        traffic = m.get("hbm_bytes_per_launch") if m.get("frames_per_launch") == F else None
         r = {"kernel": what, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-             "algorithmic_bytes_per_px": bytes_per_px, "algorithmic_bytes_per_launch": int(alg / per_step),
-             "avg_launch_ms": round(ms / per_step, 4), "launches_timed": launches, "launches_per_step": per_step,
-             "frames_per_launch": F // per_step}
+             "algorithmic_bytes_per_px": bytes_per_px, "algorithmic_bytes_per_launch": int(alg),
+             "avg_launch_ms": round(avg, 4), "launches_timed": launches, "launches_per_step": 1,
+             "frames_per_launch": F}
         if extra:
             r.update(extra)
         return r
 
     fused = stages["hyst_classify"]["launch_groups"] == 0  # canny() ran Sobel+NMS with the classify step inside
-    sn_ms, sn_n = stages["sobel_nms"]["ms_per_step"], stages["sobel_nms"]["launch_groups"]
+    sn_ms, sn_n = sn_ms_total, sn_launches  # the launches of the timed region that carried events
     if fused:
         # The pass the pipeline actually runs: s16 smoothed in (2 B/px); out: the provisional s16 edge map
         # (2 B/px, completed in place by the propagation sweeps -- there is no finalize pass) and the two 1-bit
@@ -272,20 +289,20 @@ def main():
     ctx.profile_enable(False)
     del d_sm
     roofline_s16 = roof("sobel_nms", "fused Sobel+NMS, stage-API form (s16 smoothed in, s16 suppressed magnitude out)",
-                        4.0, ms16 / max(1, n16), n16, {"timed": "after the timed region, same batch, HIP events"})
+                        4.0, ms16, n16, {"timed": "after the timed region, same batch, HIP events"})
 
     per_kernel = {
         "gaussian": roof("gaussian", "separable Gaussian, rows+columns in one kernel (u8 in, s16 out)", 3.0,
-                         stages["gaussian"]["ms_per_step"], stages["gaussian"]["launch_groups"],
+                         stages["gaussian"]["ms_per_step"] * args.steps, stages["gaussian"]["launch_groups"],
                          {"limiter": "VALU issue: separately rounded f32 mul/add chains (bit-exactness)"}),
     }
     if stages["hyst_finalize"]["launch_groups"]:
         per_kernel["hyst_finalize"] = roof("hyst_finalize", "hysteresis finalize (1-bit plane in, s16 edge map out)",
-                                           2.125, stages["hyst_finalize"]["ms_per_step"],
+                                           2.125, stages["hyst_finalize"]["ms_per_step"] * args.steps,
                                            stages["hyst_finalize"]["launch_groups"])
     if not fused:
         per_kernel["hyst_classify"] = roof("hyst_classify", "hysteresis classify (s16 in, two 1-bit planes out)", 2.25,
-                                           stages["hyst_classify"]["ms_per_step"],
+                                           stages["hyst_classify"]["ms_per_step"] * args.steps,
                                            stages["hyst_classify"]["launch_groups"])
 
     out = {
@@ -297,8 +314,8 @@ def main():
         "config": {"workload": f"{F}x {W}x{H} gray frames per GPU per step, sigma={args.sigma}, "
                                f"thresholds {args.min_val}/{args.max_val}, inputs resident in HBM",
                    "frames_per_gpu": F, "height": H, "width": W, "sigma": args.sigma,
-                   "calls": ("canny_hip_dev_canny_stream: hysteresis sweeps of step i overlap the Gaussian of step "
-                             "i+1; all K steps complete inside the timed region") if args.stream
+                   "calls": ("canny_hip_dev_canny_stream: the host checks step i's convergence after queueing the "
+                             "Gaussian of step i+1; all K steps complete inside the timed region") if args.stream
                    else "canny_hip_dev_canny (blocking)",
                    "sharding": "independent frames per GPU, no collective"},
         "roofline": roofline,

@@ -104,6 +104,7 @@ struct canny_hip_ctx {
     // default: 128 x 4K measured 2.76 ms with it against 2.72 ms without -- the Sobel+NMS kernel loses more
     // (two half-size launches, sweeps competing for its CUs) than the hidden sweeps give back.
     int overlap_hysteresis = 0;
+    int stream_overlap = 0; // canny_hip_dev_canny_stream: sweeps on the second stream (see dev_canny_stream)
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_event = nullptr, aux_event = nullptr;
     // canny_hip_dev_canny_stream: the propagation of the batch submitted last, still in flight on aux_stream
@@ -113,6 +114,8 @@ struct canny_hip_ctx {
     // profiling
     bool prof = false;
     unsigned prof_mask = ~0u; // stages whose launches get an event pair (each pair costs a few us of stream time)
+    unsigned prof_every = 1;  // ... and only every prof_every-th launch group of a stage gets one
+    unsigned prof_seen[CANNY_HIP_STAGE_COUNT] = {0};
     std::vector<EventPair> pending[CANNY_HIP_STAGE_COUNT];
     std::vector<EventPair> pool;
     double total_ms[CANNY_HIP_STAGE_COUNT] = {0};
@@ -150,22 +153,25 @@ struct StageTimer {
     EventPair ev{};
     bool on = false;
     hipStream_t stream;
-    StageTimer(canny_hip_ctx *c, int s, hipStream_t on_stream = nullptr)
-        : ctx(c), stage(s), stream(on_stream ? on_stream : c->stream)
+    bool attach; // the events are not recorded around the launches but attached to ONE dispatch (launch_events())
+    StageTimer(canny_hip_ctx *c, int s, hipStream_t on_stream = nullptr, bool attached = false)
+        : ctx(c), stage(s), stream(on_stream ? on_stream : c->stream), attach(attached)
     {
         if (!ctx->prof || !(ctx->prof_mask >> s & 1u)) return;
+        if (ctx->prof_seen[s]++ % ctx->prof_every != 0) return;
         if (!ctx->pool.empty()) {
             ev = ctx->pool.back();
             ctx->pool.pop_back();
         } else {
             if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
         }
-        on = hipEventRecord(ev.a, stream) == hipSuccess;
+        on = attach || hipEventRecord(ev.a, stream) == hipSuccess;
     }
+    LaunchEvents launch_events() const { return (on && attach) ? LaunchEvents{ev.a, ev.b} : LaunchEvents{}; }
     ~StageTimer()
     {
         if (!on) return;
-        (void)hipEventRecord(ev.b, stream);
+        if (!attach) (void)hipEventRecord(ev.b, stream);
         ctx->pending[stage].push_back(ev);
     }
 };
@@ -380,11 +386,14 @@ int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int l
 // Fused Sobel+NMS on a smoothed plane in [0,255].
 int dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int h, int w, int n, short *d_out)
 {
-    StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
-    if (ctx->sobel_nms_path != 1 && sobel_nms_march_supported(h, w))
-        HIP_TRY(ctx, launch_sobel_nms_march(d_smoothed, d_out, h, w, n, ctx->stream, ctx->tune_sobel_seg));
-    else
+    if (ctx->sobel_nms_path != 1 && sobel_nms_march_supported(h, w)) {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
+        HIP_TRY(ctx, launch_sobel_nms_march(d_smoothed, d_out, h, w, n, ctx->stream, ctx->tune_sobel_seg,
+                                            tm.launch_events()));
+    } else {
+        StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
         HIP_TRY(ctx, launch_sobel_nms(d_smoothed, d_out, h, w, n, /*domain8=*/true, ctx->stream));
+    }
     return CANNY_HIP_OK;
 }
 
@@ -425,18 +434,19 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
             B.host += 4;
             B.host_dev += 4;
             {
-                StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+                StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
                 HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, A.S, (uint64_t *)A.C, gA, lo, hi, edge_value,
-                                                             ctx->stream, ctx->tune_sobel_seg));
+                                                             ctx->stream, ctx->tune_sobel_seg, tm.launch_events()));
             }
             HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
             ctx->last_hyst_iters = 0;
             if ((rc = lane_launch_chunk(ctx, A))) return rc;
             {
-                StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+                StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
                 HIP_TRY(ctx, launch_sobel_nms_classify_march(sm + px_a, d_edges + px_a, B.S, (uint64_t *)B.C, gB, lo, hi,
-                                                             edge_value, ctx->stream, ctx->tune_sobel_seg));
+                                                             edge_value, ctx->stream, ctx->tune_sobel_seg,
+                                                             tm.launch_events()));
             }
             if ((rc = lane_launch_chunk(ctx, B))) return rc;
             for (PropLane *L : {&A, &B}) {
@@ -451,9 +461,9 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
         }
         if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc; // the kernel below writes in-image bytes only
         {
-            StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+            StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
             HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, S, C, g, lo, hi, edge_value, ctx->stream,
-                                                         ctx->tune_sobel_seg));
+                                                         ctx->tune_sobel_seg, tm.launch_events()));
         }
         // d_edges now holds the strong pixels; the sweeps add every pixel they promote: no finalize pass
         return run_propagation(ctx, g, /*speculative=*/false, []() -> int { return CANNY_HIP_OK; }, d_edges, edge_value);
@@ -472,20 +482,23 @@ int finish_pending(canny_hip_ctx *ctx)
     if ((rc = lane_wait(ctx, L))) return rc;
     while (!L.converged)
         if ((rc = lane_launch_chunk(ctx, L)) || (rc = lane_wait(ctx, L))) return rc;
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, L.event, 0));
+    if (L.stream != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, L.event, 0));
     return CANNY_HIP_OK;
 }
 
 // canny() for a stream of batches (the reference's capture loop, src/main.cpp:120-137, with batches for frames).
-// The sweeps of hysteresis are bound by launch and tile-load latency and leave most of the chip idle; here they
-// run on a second stream and the call returns with them in flight, so that the next call's Gaussian (VALU bound,
-// touches none of the hysteresis state) fills the chip beside them.  Per call:
-//   main stream:  Gaussian(i) ......... | wait P(i-1) | prepare, Sobel+NMS+classify(i) |
-//   aux stream:   P(i-1) sweeps ....... |                                              | P(i) sweeps ...
-//   host:         enqueue G(i); spin on P(i-1)'s flag (more chunks if needed); enqueue the rest; return
+// A plain call ends with a host round trip: the host learns whether the sweeps converged before it returns, and
+// the GPU idles until the next call's first kernel arrives (~20 us per call; a third of the time of a single 4K
+// frame).  Here the call returns with its chunk of sweeps queued, and the NEXT call first queues its Gaussian
+// (which touches none of the hysteresis state) and only then looks at the flag:
+//   stream:  ... S(i-1) | P(i-1) sweeps, publish | G(i) ............ | prepare, S(i) | P(i) sweeps, publish |
+//   host:                  call i: enqueue G(i); read P(i-1)'s flag (already there, or soon); enqueue the rest
+// If the flag says "not converged" (rare: more than 8 sweeps), further chunks simply run behind G(i).
+// stream_overlap = 1 puts the sweeps on a second, high-priority stream instead, so that G(i) runs BESIDE P(i-1):
+// the sweeps are latency bound and G is VALU bound, but sweep 0's waves take slots from G's 5 waves/SIMD, and a
+// 128-frame batch gains nothing (G 1.20 -> 1.37 ms for 0.26 ms of hidden sweeps).
 // The bit-planes, scheduling words and the smoothed plane stay single-buffered: everything that writes them is
-// ordered behind P(i-1) by the event join, and the Gaussian writes only the smoothed plane, which Sobel+NMS(i-1)
-// has finished reading (same stream).
+// ordered behind P(i-1), and the Gaussian writes only the smoothed plane, which S(i-1) has finished reading.
 int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int lo, int hi, int h, int w, int n,
                      short *d_edges)
 {
@@ -500,19 +513,22 @@ int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma
     if (rc) return rc;
     if ((rc = finish_pending(ctx))) return rc; // host waits here while the Gaussian runs
     HystGeom g = make_hyst_geom(h, w, n);
-    if ((rc = ensure_hyst(ctx, g)) || (rc = ensure_aux_stream(ctx))) return rc;
+    if ((rc = ensure_hyst(ctx, g)) || (ctx->stream_overlap && (rc = ensure_aux_stream(ctx)))) return rc;
     const int edge_value = 255 >= hi ? 255 : 0;
     if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc;
     {
-        StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS);
+        StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
         HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, (uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p,
-                                                     g, lo, hi, edge_value, ctx->stream, ctx->tune_sobel_seg));
+                                                     g, lo, hi, edge_value, ctx->stream, ctx->tune_sobel_seg,
+                                                     tm.launch_events()));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
     ctx->pend = main_lane(ctx, g, d_edges, edge_value);
-    ctx->pend.stream = ctx->aux_stream;
-    ctx->pend.event = ctx->aux_event;
+    if (ctx->stream_overlap) {
+        HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
+        ctx->pend.stream = ctx->aux_stream;
+        ctx->pend.event = ctx->aux_event;
+    }
     ctx->last_hyst_iters = 0;
     if ((rc = lane_launch_chunk(ctx, ctx->pend))) return rc;
     ctx->has_pend = true;
@@ -644,7 +660,14 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
     else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
     else if (!std::strcmp(name, "overlap_hysteresis") && value <= 1) ctx->overlap_hysteresis = value;
-    else if (!std::strcmp(name, "profile_stage_mask")) ctx->prof_mask = value ? (unsigned)value : ~0u;
+    else if (!std::strcmp(name, "stream_overlap") && value <= 1) {
+        int rc = bind(ctx);
+        if (rc || (rc = finish_pending(ctx))) return rc;
+        ctx->stream_overlap = value;
+    } else if (!std::strcmp(name, "profile_sample_interval") && value >= 1) {
+        ctx->prof_every = (unsigned)value;
+        for (auto &n : ctx->prof_seen) n = 0;
+    } else if (!std::strcmp(name, "profile_stage_mask")) ctx->prof_mask = value ? (unsigned)value : ~0u;
     else if (!std::strcmp(name, "tune_sobel_px") && value <= 1) sobel_nms_set_px_variant(value); // process-wide
     else if (!std::strcmp(name, "tune_plane_stores") && value <= 1) sobel_nms_set_plane_store_variant(value); // process-wide
     else if (!std::strcmp(name, "gaussian_fma_div") && value <= 1) gaussian_set_fma_div(value != 0); // process-wide

@@ -76,8 +76,14 @@ bool sobel_nms_march_supported(int height, int width);
 void sobel_nms_set_px_variant(int v); // A/B: 0 = 8 pixels per lane, 1 = 4 pixels per lane (more resident waves)
 // A/B (fused kernel): 0 = plane bytes staged in LDS for 8 rows and written as 8-byte words, 1 = direct byte stores
 void sobel_nms_set_plane_store_variant(int v);
+// An event pair attached to one kernel dispatch (hipExtLaunchKernel): that kernel's begin and end timestamps.
+// Unlike hipEventRecord before and after the launch it puts no barrier packets into the stream (those cost
+// ~30 us of stream time per pair).  Both null: plain launch.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
 hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
-                                  hipStream_t stream, int tune_seg = 0);
+                                  hipStream_t stream, int tune_seg = 0, const LaunchEvents &ev = {});
 
 // Fused Sobel+NMS+classify: the same marching kernel, but instead of the s16 suppressed magnitudes it
 // writes the two hysteresis bit-planes that launch_hyst_classify would derive from them (in-image bytes
@@ -87,7 +93,7 @@ hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int hei
 bool sobel_nms_classify_supported(int height, int width, int min_val);
 hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, int16_t *edges, uint64_t *strong, uint64_t *conn,
                                            const HystGeom &g, int min_val, int max_val, int edge_value,
-                                           hipStream_t stream, int tune_seg = 0);
+                                           hipStream_t stream, int tune_seg = 0, const LaunchEvents &ev = {});
 
 // ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
 hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,

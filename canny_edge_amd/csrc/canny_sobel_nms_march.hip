@@ -30,6 +30,8 @@
 // Precondition: smoothed values in [0,255] (what gaussian() produces), so |gx|,|gy| <= 1020.
 #include "canny_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 namespace canny {
@@ -498,8 +500,19 @@ static int plane_store_variant = 0;
 void sobel_nms_set_plane_store_variant(int v) { plane_store_variant = v; }
 
 // tune_seg: 0 = automatic, else rows per segment (A/B knob).
+// ev: optional event pair ATTACHED to the dispatch (hipExtLaunchKernel): the kernel's own begin/end timestamps,
+// without the two barrier packets that hipEventRecord before and after a launch puts into the stream.
+template <class K, class... A>
+static void launch_timed(K kernel, dim3 grid, dim3 block, hipStream_t stream, const LaunchEvents &ev, A... args)
+{
+    if (ev.start && ev.stop)
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev.start, ev.stop, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
+}
+
 static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const PlaneArgs *planes, int height, int width,
-                               int n_frames, hipStream_t stream, int tune_seg)
+                               int n_frames, hipStream_t stream, int tune_seg, const LaunchEvents &ev)
 {
     const int np = px_variant == 1 ? 2 : 4;
     const int sw = 62 * 2 * np;
@@ -516,27 +529,27 @@ static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const Plan
     const PlaneArgs pl = planes ? *planes : PlaneArgs{};
     const dim3 grid(blocks), block(SNM_WPB * 64);
     if (planes && np == 4 && plane_store_variant == 0)
-        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 4, true>), grid, block, 0, stream, smoothed, out, height,
-                           width, n_strips, n_segs, seg, (int)waves, pl);
+        launch_timed(sobel_nms_march_kernel<true, 4, true>, grid, block, stream, ev, smoothed, out, height, width,
+                     n_strips, n_segs, seg, (int)waves, pl);
     else if (planes && np == 4)
-        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 4, false>), grid, block, 0, stream, smoothed, out, height,
-                           width, n_strips, n_segs, seg, (int)waves, pl);
+        launch_timed(sobel_nms_march_kernel<true, 4, false>, grid, block, stream, ev, smoothed, out, height, width,
+                     n_strips, n_segs, seg, (int)waves, pl);
     else if (planes)
-        hipLaunchKernelGGL((sobel_nms_march_kernel<true, 2, false>), grid, block, 0, stream, smoothed, out, height,
-                           width, n_strips, n_segs, seg, (int)waves, pl);
+        launch_timed(sobel_nms_march_kernel<true, 2, false>, grid, block, stream, ev, smoothed, out, height, width,
+                     n_strips, n_segs, seg, (int)waves, pl);
     else if (np == 4)
-        hipLaunchKernelGGL((sobel_nms_march_kernel<false, 4, false>), grid, block, 0, stream, smoothed, out, height,
-                           width, n_strips, n_segs, seg, (int)waves, pl);
+        launch_timed(sobel_nms_march_kernel<false, 4, false>, grid, block, stream, ev, smoothed, out, height, width,
+                     n_strips, n_segs, seg, (int)waves, pl);
     else
-        hipLaunchKernelGGL((sobel_nms_march_kernel<false, 2, false>), grid, block, 0, stream, smoothed, out, height,
-                           width, n_strips, n_segs, seg, (int)waves, pl);
+        launch_timed(sobel_nms_march_kernel<false, 2, false>, grid, block, stream, ev, smoothed, out, height, width,
+                     n_strips, n_segs, seg, (int)waves, pl);
     return hipGetLastError();
 }
 
 hipError_t launch_sobel_nms_march(const int16_t *smoothed, int16_t *out, int height, int width, int n_frames,
-                                  hipStream_t stream, int tune_seg)
+                                  hipStream_t stream, int tune_seg, const LaunchEvents &ev)
 {
-    return launch_march(smoothed, out, nullptr, height, width, n_frames, stream, tune_seg);
+    return launch_march(smoothed, out, nullptr, height, width, n_frames, stream, tune_seg, ev);
 }
 
 bool sobel_nms_classify_supported(int height, int width, int min_val)
@@ -546,7 +559,7 @@ bool sobel_nms_classify_supported(int height, int width, int min_val)
 
 hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, int16_t *edges, uint64_t *strong, uint64_t *conn,
                                            const HystGeom &g, int min_val, int max_val, int edge_value,
-                                           hipStream_t stream, int tune_seg)
+                                           hipStream_t stream, int tune_seg, const LaunchEvents &ev)
 {
     if (!sobel_nms_classify_supported(g.height, g.width, min_val)) return hipErrorNotSupported;
     if (edge_value < 0 || edge_value > 32767) return hipErrorInvalidValue;
@@ -561,7 +574,7 @@ hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, int16_t *edg
     pl.lo1 = lo - 1;
     pl.hi1 = (hi > lo ? hi : lo) - 1;
     pl.edge_value = edge_value;
-    return launch_march(smoothed, edges, &pl, g.height, g.width, g.n_frames, stream, tune_seg);
+    return launch_march(smoothed, edges, &pl, g.height, g.width, g.n_frames, stream, tune_seg, ev);
 }
 
 } // namespace canny

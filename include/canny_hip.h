@@ -97,6 +97,9 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "overlap_hysteresis": 0 (default) / 1 -- canny() on 16 or more frames: the propagation sweeps of the first half
  *                    of the batch run on a second stream beside the Sobel+NMS kernel of the second half
  *                    (measured 1.5 % slower on 128 x 4K, kept for A/B)
+ *   "stream_overlap": 0 (default) / 1 -- canny_hip_dev_canny_stream: the sweeps left in flight run on a second,
+ *                    high-priority stream beside the next call's Gaussian instead of in order before it
+ *                    (no gain on 128 x 4K batches, kept for A/B)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
  *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide)
  *   "tune_plane_stores": 0 (default) the fused Sobel+NMS kernel stages its plane bytes in LDS and writes words,
@@ -107,7 +110,8 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "tune_finalize_mode": 0 (default) row-major hysteresis finalize, 1 tile-patch finalize (process-wide)
  *   "profile_stage_mask": bit s set = stage s (CANNY_HIP_STAGE_*) gets an event pair while profiling is enabled;
  *                    0 (default) = all stages.  Every pair costs a few microseconds of stream time, so a timed
- *                    region that needs one kernel's duration enables that stage only. */
+ *                    region that needs one kernel's duration enables that stage only.
+ *   "profile_sample_interval": N >= 1 (default 1): only every N-th launch group of a stage gets its event pair */
 int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value);
 int canny_hip_synchronize(canny_hip_ctx *ctx);
 /* Text of the last HIP runtime error seen by this context ("" if none). */
@@ -182,8 +186,9 @@ int canny_hip_dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float si
                         int height, int width, int n_frames, short *d_edges);
 /* canny() for a STREAM of batches -- the reference's capture loop (src/main.cpp:120-137: canny() on one frame
  * after the other) with resident batches in place of frames.  Same results as canny_hip_dev_canny, but the call
- * returns with the batch's hysteresis sweeps still in flight on a second stream of the context; they finish
- * beside the next call's Gaussian (the sweeps are latency bound, the Gaussian is VALU bound).  d_edges of call i
+ * returns with the batch's hysteresis sweeps still queued: the host round trip that tells a plain call whether the
+ * sweeps converged (and idles the GPU for ~20 us) happens in the next call, after that call has queued its
+ * Gaussian.  d_edges of call i
  * is complete -- for work queued on the context's stream and, after a synchronize, for the host -- once call i+1
  * or canny_hip_dev_canny_stream_flush() has returned; until then the caller must neither read nor free it.
  * d_img may be reused as soon as the context's stream has passed the call.  Every other compute entry point of

@@ -581,8 +581,10 @@ def test_canny_overlapped_halves(hip, overlap):
             c.free(d_out)
 
 
-def test_canny_stream_of_batches(hip):
-    """canny_hip_dev_canny_stream leaves each batch's sweeps in flight beside the next batch's Gaussian.  Batches
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_canny_stream_of_batches(hip, overlap):
+    """canny_hip_dev_canny_stream leaves each batch's sweeps in flight (queued before the next batch's Gaussian,
+    or with stream_overlap=1 on a second stream beside it).  Batches
     of different content (one of them needs several chunks of sweeps), separate and reused output buffers, a
     plain call in between, a shape the fused kernel does not take, and flush / synchronize as the last word."""
     h, w, n = 200, 328, 6
@@ -596,6 +598,7 @@ def test_canny_stream_of_batches(hip):
     odd = np.stack([_mixed(h, w - 3, 900 + i) for i in range(2)])
     want_odd = np.stack([oracle.canny(f, 0.3, 50, 250) for f in odd])
     with hip.Context(0) as c:
+        c.set_option("stream_overlap", overlap)
         nbytes = batches[0].nbytes
         d_in = [c.malloc(nbytes) for _ in range(2)]
         d_out = [c.malloc(nbytes * 2) for _ in range(4)]

@@ -53,19 +53,22 @@ def main():
     d_out2 = ctx.malloc(img.nbytes * 2)
     outs = (d_out, d_out2)
 
-    def loop(streamed, reps=200):
+    def loop(mode, reps=200):  # 0 blocking calls, 1 dev_canny_stream, 2 dev_canny_stream with stream_overlap
+        ctx.set_option("stream_overlap", 1 if mode == 2 else 0)
         for i in range(reps):
-            if streamed:
+            if mode:
                 ctx.dev_canny_stream(d_in, 1.4, 50, 150, H, W, 1, outs[i % 2])
             else:
                 ctx.dev_canny(d_in, 1.4, 50, 150, H, W, 1, outs[i % 2])
         ctx.synchronize()
-    t_loop = {s: timed(lambda: loop(s), 3) / 200 for s in (False, True)}
+    t_loop = {m: timed(lambda: loop(m), 3) / 200 for m in (0, 1, 2)}
+    ctx.set_option("stream_overlap", 0)
     ctx.free(d_out2)
     out["C2_stream_of_single_4k_frames"] = {
-        "blocking_calls_ms_per_frame": round(t_loop[False] * 1e3, 4),
-        "dev_canny_stream_ms_per_frame": round(t_loop[True] * 1e3, 4),
-        "dev_canny_stream_Mpix_s": round(H * W / t_loop[True] / 1e6, 1)}
+        "blocking_calls_ms_per_frame": round(t_loop[0] * 1e3, 4),
+        "dev_canny_stream_ms_per_frame": round(t_loop[1] * 1e3, 4),
+        "dev_canny_stream_overlap_ms_per_frame": round(t_loop[2] * 1e3, 4),
+        "dev_canny_stream_Mpix_s": round(H * W / t_loop[1] / 1e6, 1)}
     out["C2_single_4k_sigma1.4"] = {
         "device_resident_ms": round(t_dev * 1e3, 4), "device_resident_Mpix_s": round(H * W / t_dev / 1e6, 1),
         "host_to_host_ms": round(t_host * 1e3, 3), "host_to_host_Mpix_s": round(H * W / t_host / 1e6, 1),

@@ -644,3 +644,39 @@ def test_canny_stream_of_batches(hip, overlap):
         finally:
             for p in d_in + d_out + [d_odd_in, d_odd_out]:
                 c.free(p)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_canny_random_shapes_and_parameters(hip, seed):
+    """Seeded fuzz of the whole pipeline: shapes around the kernels' strip (496/248/240 columns), segment (32/64
+    rows) and tile (64 x 64) boundaries, widths with and without the % 8 the fused kernel wants, random sigma,
+    thresholds and batch size -- every frame bit-identical to the oracle, through both canny entry points."""
+    rng = np.random.default_rng(1000 + seed)
+    edges_w = [8, 56, 64, 72, 240, 248, 256, 488, 496, 504, 512, 736, 744, 992, 1000]
+    edges_h = [2, 3, 31, 32, 33, 63, 64, 65, 66, 127, 128, 130, 191, 193]
+    with hip.Context(0) as c:
+        for _ in range(7):
+            w = int(rng.choice(edges_w)) + int(rng.integers(-3, 4)) * int(rng.integers(0, 2))
+            h = int(rng.choice(edges_h)) + int(rng.integers(0, 3))
+            w, h = max(2, w), max(2, h)
+            n = int(rng.integers(1, 4))
+            sigma = float(rng.choice([0.4, 0.8, 1.0, 1.4, 1.7, 2.0, 2.4]))
+            lo = int(rng.integers(1, 120))
+            hi = int(rng.integers(lo + 1, 256))
+            gens = (_noise, _mixed)
+            frames = np.stack([gens[int(rng.integers(0, 2))](h, w, int(rng.integers(0, 1 << 30))) for _ in range(n)])
+            want = np.stack([oracle.canny(f, sigma, lo, hi) for f in frames])
+            d_in, d_out = c.malloc(frames.nbytes), c.malloc(frames.nbytes * 2)
+            try:
+                c.h2d(d_in, frames)
+                got = np.empty(frames.shape, np.int16)
+                c.dev_canny(d_in, sigma, lo, hi, h, w, n, d_out)
+                c.d2h(got, d_out)
+                assert np.array_equal(got, want), ("dev_canny", h, w, n, sigma, lo, hi)
+                c.dev_canny_stream(d_in, sigma, lo, hi, h, w, n, d_out)
+                c.dev_canny_stream_flush()
+                c.d2h(got, d_out)
+                assert np.array_equal(got, want), ("dev_canny_stream", h, w, n, sigma, lo, hi)
+            finally:
+                c.free(d_in)
+                c.free(d_out)

@@ -436,7 +436,7 @@ __device__ __forceinline__ uint64_t fill_runs(uint64_t p, uint64_t g)
 struct HystSched {
     unsigned *stamp, *queue0, *queue1, *count;
 };
-constexpr int kSweep0Tiles = 4; // tiles per wave in sweep 0
+constexpr int kSweep0Tiles = 2; // tiles per wave in sweep 0
 __device__ __forceinline__ HystSched make_sched(unsigned *words, int tiles)
 {
     HystSched s;
@@ -573,7 +573,7 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
     process_tile(t, lane, strong, sch, last_change, iter, g, edges, edge_value, c, in);
 }
 
-// Sweep 0 visits every tile (grid = tiles/4 workgroups); later sweeps are launched with a small fixed
+// Sweep 0 visits every tile (grid = tiles / (4 kSweep0Tiles) workgroups); later sweeps are launched with a small fixed
 // grid whose waves walk the work queue, so a sweep with little or nothing to do costs one short launch
 // instead of 130 k waves that each read a stamp and exit.
 __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restrict__ strong,
@@ -589,9 +589,10 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
     const HystSched sch = make_sched(sched_words, tiles);
     if (wave == 0 && lane == 0) sch.count[(iter + 2) % 3] = 0; // the slot sweep iter+1 will append to
     if (iter == 0) {
-        // Four tiles per wave, their connectable words loaded up front: most tiles are empty and cost exactly
-        // this one load, so what matters is how many of them are in flight (a wave per tile was bound by the
-        // latency of 130 k single loads).
+        // kSweep0Tiles tiles per wave, their connectable words loaded up front: a third of the tiles are empty
+        // and cost exactly this one load.  Measured per 128 x 4K batch (all sweeps): 1 tile per wave 0.254 ms,
+        // 2: 0.231, 3: 0.229, 4: 0.244, 8: 0.249 -- more tiles per wave mean fewer, longer-lived waves whose
+        // tile chains (connectable word -> strong word + halo -> flood -> store) run one after the other.
         for (int t0 = wave * kSweep0Tiles; t0 < tiles; t0 += n_waves * kSweep0Tiles) {
             uint64_t c[kSweep0Tiles];
 #pragma unroll

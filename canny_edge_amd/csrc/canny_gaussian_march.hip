@@ -672,6 +672,11 @@ static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, i
     while (target > 32 &&
            (long long)n_frames * n_strips * ((height + seg_for(target) - 1) / seg_for(target)) < 16384)
         target >>= 1;
+    // a single frame leaves most SIMDs without a wave even then: shorter segments still (down to one loop trip,
+    // i.e. up to half the rows of a wave are halo) as long as that gives idle SIMDs something to do
+    while (target > 8 &&
+           (long long)n_frames * n_strips * ((height + seg_for(target) - 1) / seg_for(target)) < 2048)
+        target >>= 1;
     int seg = seg_for(tune_seg_target >= 8 ? tune_seg_target : target);
     int n_segs = (height + seg - 1) / seg;
     long long waves = (long long)n_frames * n_strips * n_segs;

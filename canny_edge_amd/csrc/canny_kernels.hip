@@ -930,7 +930,11 @@ hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigne
                                  int iter, const HystGeom &g, hipStream_t stream, int16_t *edges, int edge_value)
 {
     unsigned blocks = (unsigned)((g.tiles() + 4 * kSweep0Tiles - 1) / (4 * kSweep0Tiles)); // sweep 0: all tiles
-    if (iter > 0 && blocks > 1024u) blocks = 1024u; // queue walkers: 16 waves per CU
+    if (iter > 0) { // queue walkers: at most 16 waves per CU, and no more than a wave per 4 tiles (a single frame's
+                    // 2040 tiles: 128 workgroups instead of 1024, whose dispatch alone took 4 of a sweep's 9 us)
+        const unsigned want = (unsigned)((g.tiles() + 15) / 16);
+        blocks = want < 8u ? 8u : (want > 1024u ? 1024u : want);
+    }
     hipLaunchKernelGGL(hyst_propagate_kernel, dim3(blocks), dim3(256), 0, stream, strong, conn, stamp, last_change,
                        iter, g, edges, edge_value);
     return hipGetLastError();

@@ -521,7 +521,10 @@ static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const Plan
     // 0.490 at 128 rows and 0.589 at 256); 32 rows only when that is what it takes to give the chip enough waves
     int seg = 64;
     while (seg > 32 && (long long)n_frames * n_strips * ((height + seg - 1) / seg) < 16384) seg >>= 1;
+    // a single frame: fewer waves than SIMDs even then -- latency, not throughput, is what is left to win
+    while (seg > 8 && (long long)n_frames * n_strips * ((height + seg - 1) / seg) < 2048) seg >>= 1;
     if (tune_seg >= 8) seg = tune_seg;
+    if (planes) seg = (seg + 7) & ~7; // the staged plane bytes leave in groups of 8 rows that must not straddle waves
     int n_segs = (height + seg - 1) / seg;
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;

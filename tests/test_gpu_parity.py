@@ -680,3 +680,24 @@ def test_canny_random_shapes_and_parameters(hip, seed):
             finally:
                 c.free(d_in)
                 c.free(d_out)
+
+
+@pytest.mark.parametrize("seg", [8, 12, 20, 33, 100])
+def test_canny_with_any_sobel_segment_length(hip, seg, sobel_px):
+    """tune_sobel_seg is free-form; the fused kernel's staged plane bytes leave in groups of 8 rows, so the launcher
+    rounds what it is given -- whatever the knob says, the result is the oracle's."""
+    h, w, n = 150, 1000, 2
+    frames = np.stack([_mixed(h, w, 40 + i) for i in range(n)])
+    want = np.stack([oracle.canny(f, 1.0, 40, 120) for f in frames])
+    with hip.Context(0) as c:
+        c.set_option("tune_sobel_seg", seg)
+        d_in, d_out = c.malloc(frames.nbytes), c.malloc(frames.nbytes * 2)
+        try:
+            c.h2d(d_in, frames)
+            c.dev_canny(d_in, 1.0, 40, 120, h, w, n, d_out)
+            got = np.empty(frames.shape, np.int16)
+            c.d2h(got, d_out)
+            assert np.array_equal(got, want)
+        finally:
+            c.free(d_in)
+            c.free(d_out)

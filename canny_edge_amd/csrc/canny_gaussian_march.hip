@@ -382,25 +382,45 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 #pragma unroll
                     for (int a = 0; a <= C; a++) Q[i][a] = __fmul_rn(v[i], T[a]);
             }
+            // The leading terms of output i -- the pixels left of this lane -- are summed by the LEFT neighbour
+            // (same operands, same order, so the same bits) and arrive as one value whose wave shift folds into
+            // the next add: every lane therefore computes pre[i] for its right neighbour.  Without this each of the
+            // 4 outputs starts with a bare v_mov_b32_dpp and the two-lane hop costs another.
+            float pre[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float s = 0.0f;
 #pragma unroll
                 for (int d = -C; d <= C; d++) {
+                    const int e = i + d + 4, a = d < 0 ? -d : d; // the right neighbour's pixel i+d is my pixel e
+                    if (e >= 4) continue;                        // ... its own pixels and beyond: not mine to add
+                    const float term = e >= 0 ? Q[e][a] : lane_shr1(Q[e + 4][a]); // e < 0: from my own left
+                    s = (d == -C) ? term : __fadd_rn(s, term);
+                }
+                pre[i] = s;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float s = 0.0f;
+                bool open = false; // no term yet
+                if (i - C < 0) {
+                    s = lane_shr1(pre[i]);
+                    open = true;
+                }
+#pragma unroll
+                for (int d = -C; d <= C; d++) {
                     const int e = i + d, a = d < 0 ? -d : d; // pixel e (relative to x0) at distance a
+                    if (e < 0) continue;                      // in pre[i]
                     float term;
-                    if (e >= 0 && e < 4) {
+                    if (e < 4) {
                         term = Q[e][a];
-                    } else if (e < 0) {
-                        const int hop = (3 - e) / 4;
-                        term = lane_shr1(Q[e + 4 * hop][a]);
-                        if (hop == 2) term = lane_shr1(term);
                     } else {
                         const int hop = e / 4;
                         term = lane_shl1(Q[e - 4 * hop][a]);
                         if (hop == 2) term = lane_shl1(term);
                     }
-                    s = (d == -C) ? term : __fadd_rn(s, term);
+                    s = open ? __fadd_rn(s, term) : term;
+                    open = true;
                 }
                 res[i] = FMA_DIV ? __fmaf_rn(s, fma_c, s) : div_by(s, cnt_h[i], inv_h[i]);
             }

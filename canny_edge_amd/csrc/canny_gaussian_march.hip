@@ -278,15 +278,6 @@ __device__ __forceinline__ float lane_shl1(float v) // lane L <- lane L+1, lane 
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
-// A lane offset the optimiser cannot fold into a loop-invariant 64-bit VGPR pointer: the address stays
-// "uniform row base (SGPR pair) + 32-bit lane offset", which is global_load/store's saddr form; otherwise
-// every row pays a v_mad_u64_u32 and friends to add the row offset to a per-lane pointer.
-__device__ __forceinline__ uint32_t opaque_offset(uint32_t v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 template <class F, int... I>
 __device__ __forceinline__ void for_each_phase(F &&f, std::integer_sequence<int, I...>)
 {
@@ -339,12 +330,20 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         }
     }
 
+    // Lane offsets of the row loads and stores, passed through an empty asm at every use: the optimiser then cannot
+    // fold them into loop-invariant 64-bit VGPR pointers, and the addresses stay "uniform row base (SGPR pair) +
+    // 32-bit lane offset" (saddr form).  Because the variable itself is what the asm "changes", its old value is
+    // dead at that point and no register copy is needed (opaque_offset() on a loop-invariant value costs a v_mov
+    // per use).  Both are only used where x0 >= 0.
+    uint32_t ld_off = (uint32_t)x0, st_off = 2u * (uint32_t)x0;
+
     auto load_row = [&](int r) -> uint32_t {
         if (ROW_EDGE && (r < 0 || r >= H)) return 0u; // wave-uniform
         const uint8_t *p = jb.fimg + (size_t)r * W; // wave-uniform
         uint32_t v = 0u;
         if (!COL_EDGE || full4) {
-            __builtin_memcpy(&v, p + opaque_offset((uint32_t)x0), 4); // x0 >= 0 here
+            asm volatile("" : "+v"(ld_off)); // see ld_off
+            __builtin_memcpy(&v, p + ld_off, 4);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -467,13 +466,14 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         const int o0 = (int)quot(acc[DONE][0]), o1 = (int)quot(acc[DONE][1]);
         const int o2 = (int)quot(acc[DONE][2]), o3 = (int)quot(acc[DONE][3]);
         uint2 pk;
-        pk.x = (uint32_t)(uint16_t)o0 | ((uint32_t)(uint16_t)o1 << 16);
-        pk.y = (uint32_t)(uint16_t)o2 | ((uint32_t)(uint16_t)o3 << 16);
+        // quotients of non-negative sums: 0 <= o < 65536, so the low halves need no mask (one v_lshl_or_b32 per pair)
+        pk.x = (uint32_t)o0 | ((uint32_t)o1 << 16);
+        pk.y = (uint32_t)o2 | ((uint32_t)o3 << 16);
         asm volatile("" : "+v"(pk.x), "+v"(pk.y)); // materialise here, whatever the branch below does
         if (in_seg && owner) {
             // owner lanes have x0 >= 0; byte offset so that no 64-bit shift is needed per lane
-            int16_t *dst = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(jb.fout + (size_t)y * W) +
-                                                       opaque_offset(2u * (uint32_t)x0));
+            asm volatile("" : "+v"(st_off));
+            int16_t *dst = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(jb.fout + (size_t)y * W) + st_off);
             if (!COL_EDGE || full4) {
                 __builtin_memcpy(dst, &pk, 8);
             } else {

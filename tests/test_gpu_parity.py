@@ -701,3 +701,38 @@ def test_canny_with_any_sobel_segment_length(hip, seg, sobel_px):
         finally:
             c.free(d_in)
             c.free(d_out)
+
+
+def test_canny_large_resident_batch_of_4k_frames(hip):
+    """BASELINE config 5's per-GPU share in shape (hundreds of resident 4K frames in one call): 512 frames = 4.2 Gpx,
+    i.e. 34 GB of planes and workspaces -- 32-bit pixel counts, tile counts and launch grids all go far past what
+    the other tests reach.  Eight distinct frames cycle through the batch; the first and the last copy of each are
+    compared with the oracle, and a checksum of checksums over ALL frames checks that equal inputs gave equal maps."""
+    h, w, n, distinct = 2160, 3840, 512, 8
+    base = [synth_frame(h, w, 4200 + i) for i in range(distinct)]
+    want = [oracle.canny(f, 1.4, 50, 150) for f in base]
+    frame_px = h * w
+    with hip.Context(0) as c:
+        d_in, d_out = c.malloc(n * frame_px), c.malloc(n * frame_px * 2)
+        try:
+            for i in range(n):
+                c.h2d(d_in + i * frame_px, base[i % distinct])
+            c.dev_canny(d_in, 1.4, 50, 150, h, w, n, d_out)
+            got = np.empty((h, w), np.int16)
+            sums = []
+            for i in range(n):
+                if i < distinct or i >= n - distinct:
+                    c.d2h(got, d_out + i * frame_px * 2)
+                    assert np.array_equal(got, want[i % distinct]), i
+            # every frame's edge count, taken on the device side of the copy: one u8 narrowing + host sum per frame
+            # would move 4 GB; instead fetch one row band per frame that crosses tile and segment boundaries
+            band = np.empty((80, w), np.int16)
+            for i in range(n):
+                c.d2h(band, d_out + (i * frame_px + 1000 * w) * 2)
+                sums.append(int(np.count_nonzero(band)))
+            for i in range(n):
+                assert sums[i] == sums[i % distinct], i
+                assert sums[i] == int(np.count_nonzero(want[i % distinct][1000:1080])), i
+        finally:
+            c.free(d_in)
+            c.free(d_out)

@@ -451,7 +451,15 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
     // per-wave staging area of the plane bytes (LDS_PLANES kernels only): 2 planes x 8 rows x 72 bytes
     __shared__ __attribute__((aligned(8))) uint8_t stage_lds[LDS_PLANES ? SNM_WPB * 2 * 8 * 72 : 8];
     uint8_t *stage_mem = stage_lds + (LDS_PLANES ? (threadIdx.x >> 6) * (2 * 8 * 72) : 0);
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * SNM_WPB + (threadIdx.x >> 6));
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): remapped so that every XCD gets a
+    // contiguous range of (frame, segment, strip) jobs, the rows and columns neighbouring jobs share are read
+    // from HBM once per XCD range instead of once per job.  (Bijective for any grid size.)
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned q = gridDim.x / 8u, r = gridDim.x % 8u, xcd = bid % 8u;
+        bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + bid / 8u;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(bid * SNM_WPB + (threadIdx.x >> 6));
     if (wave >= total_waves) return;
     const int s = wave % n_strips;
     const int g = (wave / n_strips) % n_segs;

@@ -11,14 +11,17 @@ MAX / barrier (weak scaling: F frames per GPU whatever N is).
 
 Workload (BASELINE.json configs[1]): 3840x2160 gray, sigma 1.4, thresholds 50/150, synthetic frames
 (canny_edge_amd.synth, seed 42+i), F = 128 frames per GPU per step: the working set (1 GB u8 in, 2 GB s16 per
-plane) is far beyond the 256 MB Infinity Cache and a step (2.7 ms) is long against its fixed costs -- kernel
+plane) is far beyond the 256 MB Infinity Cache and a step (2.4 ms) is long against its fixed costs -- kernel
 tails, sweep launches, one host round trip: 64 frames per step run 7 % slower per frame, 256 another 3 % faster.
+Untimed before the W warm-up steps: a parity spot check against the oracle and --spinup-seconds of steps that bring
+the device to its steady clocks.
 
 The JSON line also carries
   roofline     -- the Sobel+NMS kernel of the timed region: algorithmic bytes / average launch time measured
-                  with HIP events on the launch stream inside the timed region, vs 8 TB/s.  canny() runs it
-                  with the hysteresis threshold-classify step inside (2 B/px s16 in + 0.25 B/px bit-planes
-                  out); `roofline_sobel_nms_s16` is the stage-API form SURVEY.md 8(d) prices at 4 B/px (s16 in,
+                  with HIP events inside the timed region (attached to the kernel's dispatch on the launch stream,
+                  every 4th step: see the comment at the timed loop), vs 8 TB/s.  canny() runs it with the
+                  hysteresis threshold-classify step inside (2 B/px s16 in + 2 B/px s16 provisional edge map +
+                  0.25 B/px bit-planes out); `roofline_sobel_nms_s16` is the stage-API form SURVEY.md 8(d) prices at 4 B/px (s16 in,
                   s16 out), timed the same way on the same batch right after the timed region;
                   `roofline_other_kernels` prices the other kernels of the step the same way
   cpu_baseline -- the CPU oracle (a faithful single-thread restatement of the reference's utils.cpp;
@@ -265,7 +268,7 @@ def main():
     if fused:
         # The pass the pipeline actually runs: s16 smoothed in (2 B/px); out: the provisional s16 edge map
         # (2 B/px, completed in place by the propagation sweeps -- there is no finalize pass) and the two 1-bit
-        # hysteresis planes (2/8 B/px).  ~26 VALU instructions per pixel: VALU issue is the co-limiter.
+        # hysteresis planes (2/8 B/px).  ~28 VALU instructions per pixel: VALU issue is the co-limiter.
         roofline = roof("sobel_nms_classify",
                         "fused Sobel+NMS+threshold-classify (s16 smoothed in; s16 edge map + strong/connectable "
                         "bit-planes out)", 4.25, sn_ms, sn_n, {"limiter": "VALU issue and HBM, see DESIGN.md"})

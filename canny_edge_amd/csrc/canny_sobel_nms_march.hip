@@ -90,6 +90,7 @@ struct SnmCfg {
     static constexpr int PX = 2 * NP;  // pixels per lane
     static constexpr int SW = 62 * PX; // output columns per strip (lanes 0 and 63 are halo lanes)
 };
+constexpr int SNM_STAGE_ROWS = 64; // rows of plane bytes a wave can park in LDS = longest segment of the fused kernel
 constexpr int SNM_WPB = 4;          // waves per workgroup (independent of each other)
 
 template <int N>
@@ -182,87 +183,60 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
         for (int e = 0; e < PX; e++) cP[a][e] = cQ[a][e] = 0.0f;
     }
 
-    // ---- plane bytes through LDS (interior strips of the 8-pixel PLANES kernel) -----------------------------
+    // ---- plane bytes through LDS (the 8-pixel PLANES kernel) ---------------------------------------------------
     // A lane's plane byte belongs to a 64-bit plane word shared with seven other lanes, and consecutive rows of
     // a tile are consecutive words: stored directly, every row costs two byte-store instructions that hit eight
-    // or nine tiles.  Instead the wave keeps eight rows of its 62 bytes per plane in LDS (row pitch 72 bytes =
-    // nine words, byte column = position in the first word + lane) and then writes them out with one 8-byte store
-    // per (row, full word) and one 2-byte store per leftover pair: four store instructions per eight rows instead
-    // of sixteen.  LDS instructions do not count in vmcnt, which is what the row loop stalls on.
-    // Border strips (COL_EDGE) own fewer than 62 bytes in the last strip and possibly an odd number: their
-    // leftovers are written byte by byte, one instruction for the first partial word and one for the last.
+    // or nine tiles, and stores are what this kernel's row loop stalls on.  Instead the wave parks the
+    // bytes of its whole segment in LDS (up to 64 rows x 72 bytes per plane; byte column = position in the strip's
+    // first plane word + lane) and writes them out once, after the last row, with LANE = ROW: an 8-byte store per
+    // complete word column then covers 64 consecutive words of one tile -- 512 contiguous bytes -- and the strip's
+    // ragged ends go out as byte pairs (interior strips: the strip starts on an even byte) or single bytes (border
+    // strips).  ~20 store instructions per segment, none of them inside the row loop.
     constexpr bool STAGE = LDS_PLANES && PLANES && NP == 4;
-    constexpr unsigned kStagePitch = 72, kStagePlane = 8 * kStagePitch;
+    constexpr unsigned kStagePitch = 72, kStageRows = SNM_STAGE_ROWS, kStagePlane = kStageRows * kStagePitch;
     uint8_t *const stage = stage_mem;
-    unsigned stage_col = 0, fw_lds = 0, fw_gl = 0, pc_lds = 0, pc_gl = 0, pl_lds = 0, pl_gl = 0;
-    int fw_j = 99, pc_j = 99, pl_j = 99; // row of the group this lane writes in each role; 99 = no such role
+    unsigned stage_col = 0;
+    int st_o = 0, st_e = 0, st_w0 = 0; // owned byte columns [st_o, st_e) of a staged row; tile column of its first word
     if (STAGE) {
         const int strip_b0 = (x0 - (jb.lane - 1) * PX) >> 3; // byte column of lane 1 (wave-uniform, even)
-        const int o = strip_b0 & 7, w0 = strip_b0 >> 3;      // position in its plane word, tile column of that word
         const int nb = COL_EDGE ? max(0, min(62, (W >> 3) - strip_b0)) : 62; // bytes owned (lanes 1..nb)
-        const int e = o + nb;                                 // owned byte columns of a staged row: [o, e)
-        stage_col = jb.lane == 0 ? 71u : (unsigned)(o + jb.lane - 1); // non-owner lanes land in bytes nobody reads
-        const int j = jb.lane >> 3, q = jb.lane & 7;
-        // complete words: from the first word boundary at or after o up to e
-        const int wfull = q + (o ? 1 : 0);
-        if (q < 7 && 8 * wfull + 8 <= e) {
-            fw_j = j;
-            fw_lds = (unsigned)j * kStagePitch + (unsigned)wfull * 8u;
-            fw_gl = (unsigned)(w0 + wfull) * 512u + (unsigned)j * 8u;
-        }
-        if (!COL_EDGE) {
-            // interior strip: the other 6 bytes are three byte pairs at the strip's ends (o is even): lanes 0..23
-            if (jb.lane < 24) {
-                const int p = jb.lane % 3, n_first = ((8 - o) >> 1) & 3;
-                const int i = p < n_first ? o + 2 * p : 8 * (e >> 3) + 2 * (p - n_first);
-                pc_j = jb.lane / 3;
-                pc_lds = (unsigned)pc_j * kStagePitch + (unsigned)i;
-                pc_gl = (unsigned)(w0 + (i >> 3)) * 512u + (unsigned)pc_j * 8u + (unsigned)(i & 7);
-            }
-        } else {
-            // first partial word: bytes [o, min(8, e)) when o > 0; last partial word: bytes [8*wl, e) when it is
-            // not complete and not the first word again (or when the strip starts on a word boundary)
-            const int wl = e >> 3;
-            if (o > 0 && q >= o && q < min(8, e)) {
-                pc_j = j;
-                pc_lds = (unsigned)j * kStagePitch + (unsigned)q;
-                pc_gl = (unsigned)w0 * 512u + (unsigned)j * 8u + (unsigned)q;
-            }
-            if ((wl > 0 || o == 0) && q < (e & 7)) {
-                pl_j = j;
-                pl_lds = (unsigned)j * kStagePitch + (unsigned)(8 * wl + q);
-                pl_gl = (unsigned)(w0 + wl) * 512u + (unsigned)j * 8u + (unsigned)q;
-            }
-        }
+        st_o = strip_b0 & 7;
+        st_w0 = strip_b0 >> 3;
+        st_e = st_o + nb;
+        stage_col = jb.lane == 0 ? 71u : (unsigned)(st_o + jb.lane - 1); // non-owner lanes land in bytes nobody reads
     }
-    auto stage_flush = [&](int y2) { // y2 = last row staged: rows (y2 & ~7) .. y2 go out
-        const int jmax = y2 & 7;
-        const unsigned gbase = (unsigned)(y2 >> 6) * (unsigned)jb.tiles_x * 512u + (unsigned)((y2 & 63) & ~7) * 8u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // compiler: the byte writes above come first
-        if (fw_j <= jmax) {
-            const uint64_t wc = *reinterpret_cast<const uint64_t *>(stage + fw_lds);
-            const uint64_t ws = *reinterpret_cast<const uint64_t *>(stage + kStagePlane + fw_lds);
-            *reinterpret_cast<uint64_t *>(jb.pconn + gbase + fw_gl) = wc;
-            *reinterpret_cast<uint64_t *>(jb.pstrong + gbase + fw_gl) = ws;
-        }
-        if (!COL_EDGE) {
-            if (pc_j <= jmax) {
-                const uint16_t hc = *reinterpret_cast<const uint16_t *>(stage + pc_lds);
-                const uint16_t hs = *reinterpret_cast<const uint16_t *>(stage + kStagePlane + pc_lds);
-                *reinterpret_cast<uint16_t *>(jb.pconn + gbase + pc_gl) = hc;
-                *reinterpret_cast<uint16_t *>(jb.pstrong + gbase + pc_gl) = hs;
-            }
-        } else {
-            if (pc_j <= jmax) {
-                jb.pconn[gbase + pc_gl] = stage[pc_lds];
-                jb.pstrong[gbase + pc_gl] = stage[kStagePlane + pc_lds];
-            }
-            if (pl_j <= jmax) {
-                jb.pconn[gbase + pl_gl] = stage[pl_lds];
-                jb.pstrong[gbase + pl_gl] = stage[kStagePlane + pl_lds];
+    auto stage_flush_segment = [&]() { // after the segment's last row
+        const int y = ybeg + jb.lane;  // lane = row
+        const bool row_ok = y < yend;
+        const unsigned lrow = (unsigned)jb.lane * kStagePitch;
+        const unsigned grow = (unsigned)(y >> 6) * (unsigned)jb.tiles_x * 512u + (unsigned)(y & 63) * 8u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // compiler: the rows' byte writes come first
+        const int wf0 = (st_o + 7) >> 3, wf1 = st_e >> 3; // plane words [wf0, wf1) lie entirely inside [st_o, st_e)
+        for (int k = wf0; k < wf1; k++) {                 // wave-uniform, at most 8 trips
+            if (row_ok) {
+                const unsigned g = grow + (unsigned)(st_w0 + k) * 512u;
+                *reinterpret_cast<uint64_t *>(jb.pconn + g) = *reinterpret_cast<const uint64_t *>(stage + lrow + 8 * k);
+                *reinterpret_cast<uint64_t *>(jb.pstrong + g) =
+                    *reinterpret_cast<const uint64_t *>(stage + kStagePlane + lrow + 8 * k);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // ... and the next group's writes come after
+        auto leftover = [&](int i) { // byte column i (and i + 1 in interior strips, where everything is even)
+            if (!row_ok) return;
+            const unsigned g = grow + (unsigned)(st_w0 + (i >> 3)) * 512u + (unsigned)(i & 7);
+            if (!COL_EDGE) {
+                *reinterpret_cast<uint16_t *>(jb.pconn + g) = *reinterpret_cast<const uint16_t *>(stage + lrow + i);
+                *reinterpret_cast<uint16_t *>(jb.pstrong + g) =
+                    *reinterpret_cast<const uint16_t *>(stage + kStagePlane + lrow + i);
+            } else {
+                jb.pconn[g] = stage[lrow + i];
+                jb.pstrong[g] = stage[kStagePlane + lrow + i];
+            }
+        };
+        constexpr int kStep = COL_EDGE ? 1 : 2;
+        const int head_end = min(8 * wf0, st_e), tail_beg = max(8 * wf1, head_end);
+        for (int i = st_o; i < head_end; i += kStep) leftover(i);
+        for (int i = tail_beg; i < st_e; i += kStep) leftover(i);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
 
     // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
@@ -397,11 +371,10 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                     sb |= from_right(sb) << 4;
                 }
                 if (STAGE) {
-                    // plane bytes: staged in LDS for eight rows, then written as whole 8-byte words (see stage_flush)
-                    const unsigned rowoff = (unsigned)(y2 & 7) * kStagePitch;
+                    // plane bytes: parked in LDS until the segment is done (see stage_flush_segment)
+                    const unsigned rowoff = (unsigned)(y2 - ybeg) * kStagePitch;
                     stage[rowoff + stage_col] = (uint8_t)cbits; // halo lanes write pad columns nobody reads
                     stage[kStagePlane + rowoff + stage_col] = (uint8_t)sb;
-                    if ((y2 & 7) == 7 || y2 == yend - 1) stage_flush(y2);
                     if (owner) __builtin_memcpy(jb.fout + (size_t)y2 * W + x0, outp, 4 * NP);
                 } else if (owner) { // W % 8 == 0: an owner lane's pixels are all inside the image
                     if (NP == 4 || (jb.lane & 1)) {
@@ -442,6 +415,9 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
         load_row(r + 4, pb);
         step(IC<2>{}, r + 2, pc);
     }
+    // Every row below yend has been staged by now; the row loop's state is dead here, so the flush's own
+    // registers come for free (called from inside the loop it pushed the kernel from 160 to 215 VGPRs).
+    if (STAGE) stage_flush_segment();
 }
 
 } // namespace
@@ -459,9 +435,9 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
 {
     // readfirstlane tells the compiler what it cannot prove: everything derived from the wave index is
     // wave-uniform, so rows, segments and border tests live in SGPRs and branch with s_cbranch.
-    // per-wave staging area of the plane bytes (LDS_PLANES kernels only): 2 planes x 8 rows x 72 bytes
-    __shared__ __attribute__((aligned(8))) uint8_t stage_lds[LDS_PLANES ? SNM_WPB * 2 * 8 * 72 : 8];
-    uint8_t *stage_mem = stage_lds + (LDS_PLANES ? (threadIdx.x >> 6) * (2 * 8 * 72) : 0);
+    // per-wave staging area of the plane bytes (LDS_PLANES kernels only): 2 planes x 64 rows x 72 bytes
+    __shared__ __attribute__((aligned(8))) uint8_t stage_lds[LDS_PLANES ? SNM_WPB * 2 * SNM_STAGE_ROWS * 72 : 8];
+    uint8_t *stage_mem = stage_lds + (LDS_PLANES ? (threadIdx.x >> 6) * (2 * SNM_STAGE_ROWS * 72) : 0);
     // edge-map table of the LDS_PLANES kernel: entry b = the eight s16 pixels of strong-bit byte b
     __shared__ uint4 edge_lut[LDS_PLANES ? 256 : 1];
     if (LDS_PLANES) {
@@ -556,7 +532,7 @@ static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const Plan
     // a single frame: fewer waves than SIMDs even then -- latency, not throughput, is what is left to win
     while (seg > 8 && (long long)n_frames * n_strips * ((height + seg - 1) / seg) < 2048) seg >>= 1;
     if (tune_seg >= 8) seg = tune_seg;
-    if (planes) seg = (seg + 7) & ~7; // the staged plane bytes leave in groups of 8 rows that must not straddle waves
+    if (planes && np == 4 && plane_store_variant == 0 && seg > SNM_STAGE_ROWS) seg = SNM_STAGE_ROWS; // a segment's plane bytes are parked in LDS
     int n_segs = (height + seg - 1) / seg;
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -102,8 +102,8 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *                    (no gain on 128 x 4K batches, kept for A/B)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
  *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide)
- *   "tune_plane_stores": 0 (default) the fused Sobel+NMS kernel stages its plane bytes in LDS and writes words,
- *                    1 direct byte stores (process-wide)
+ *   "tune_plane_stores": 0 (default) the fused Sobel+NMS kernel parks a segment's plane bytes in LDS and writes
+ *                    them as whole words after its last row, 1 direct byte stores (process-wide)
  *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel with the row-pass product table in LDS,
  *                    1 LDS-ring marching kernel, 2 symmetric-tap kernel that multiplies (process-wide)
  *   "tune_gaussian_seg": approximate rows per wave segment of the marching Gaussian, 0 = automatic (process-wide)

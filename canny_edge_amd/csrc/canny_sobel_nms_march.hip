@@ -69,18 +69,31 @@ __device__ __forceinline__ uint32_t from_right(uint32_t v)
 // straight into the upper half of the output pair, which saves the v_cvt_pk_u16_u32 per pixel pair.
 __device__ __forceinline__ void keep_gt_hi(uint32_t &pair, int a, int b, int zero)
 {
+    // (gfx940+: a VALU that reads an SGPR or VCC another VALU has just written needs two wait states in between;
+    // nothing inside an asm string is padded by the compiler)
     asm("v_cmp_gt_i32 vcc, %1, %2\n\t"
+        "s_nop 1\n\t"
         "v_cndmask_b32_sdwa %0, %3, %1, vcc dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
         : "+v"(pair)
         : "v"(a), "v"(b), "v"(zero)
         : "vcc");
 }
 
-// bits = 2*bits + (a > b): v_cmp + v_addc.  (Written in C the compiler builds each bit with v_cndmask and
-// merges them with shifts and v_or3: three instructions per bit instead of two.)
-__device__ __forceinline__ void push_gt(unsigned &bits, int a, int b)
+// cbits = 2*cbits + (a > b), sbits = 2*sbits + (a > c) with a wave-uniform c: v_cmp + v_addc per bit.  (Written
+// in C the compiler builds each bit with v_cndmask and merges them with shifts and v_or3: three instructions per
+// bit instead of two.)  The two compares come first, so that each carry-in is read two wait states after the
+// compare that wrote it (gfx940+ hazard: VALU writes SGPR/VCC -> VALU reads it) at the price of one s_nop.
+__device__ __forceinline__ void push_gt2(unsigned &cbits, unsigned &sbits, int a, int b, int c)
 {
-    asm("v_cmp_gt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(a), "v"(b) : "vcc");
+    unsigned long long m; // the second compare's lane mask
+    asm("v_cmp_gt_i32 vcc, %3, %4\n\t"
+        "v_cmp_gt_i32 %2, %3, %5\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+        "v_addc_co_u32 %1, %2, %1, %1, %2"
+        : "+v"(cbits), "+v"(sbits), "=&s"(m)
+        : "v"(a), "v"(b), "s"(c)
+        : "vcc");
 }
 
 // NP = packed s16 pairs per lane: 4 (8 pixels, 16-byte accesses, ~146 VGPRs: 3 waves per SIMD) or 2 (4 pixels,
@@ -338,8 +351,8 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                 const int nb = v_ge0 ? n135 : n90;
                 const int nsel = u_ge0 ? na : nb;
                 if (PLANES) {
-                    push_gt(cbits, mc, nsel);   // survived NMS and mc >= min_val
-                    push_gt(sbits, mc, jb.hi1); // mc >= max(min_val, max_val); ANDed with cbits below
+                    // cbits: survived NMS and mc >= min_val;  sbits: mc >= max(min_val, max_val), ANDed with cbits below
+                    push_gt2(cbits, sbits, mc, nsel, jb.hi1);
                 } else if ((e & 1) == 0) {
                     outp[e >> 1] = (uint32_t)((mc > nsel) ? mc : 0); // magnitudes are < 65536: upper half zero
                 } else {

@@ -56,6 +56,27 @@ struct DevBuf {
     }
 };
 
+struct PinBuf { // page-locked host staging
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipHostMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
 struct EventPair {
     hipEvent_t a, b;
 };
@@ -88,6 +109,20 @@ struct canny_hip_ctx {
     int sobel_nms_path = 0;  // 0 auto, 1 LDS tile, 2 march
     int tune_sobel_seg = 0;  // A/B knob of the marching Sobel+NMS kernel: rows per segment, 0 = automatic
     int fuse_classify = 1;   // canny(): Sobel+NMS emits the hysteresis bit-planes directly when it can
+    // canny_hip_canny_batch: host threads (= streams) that each take every n-th chunk, and megabytes of input per
+    // chunk.  0 = automatic: 2 x 24 MB between pinned buffers (1024 x 1080p: 93 ms against 108 ms with 3 x 64 MB;
+    // a third stream only makes the two DMA directions wait for each other), 4 x 16 MB when a pageable buffer has
+    // to be staged by the worker threads (183 ms against 280 ms with 3 x 64 MB).
+    int batch_workers = 0;
+    int batch_chunk_mb = 0;
+    // the batch pipeline's workers live as long as the context: creating a sub-context with its stream and
+    // allocating its staging cost ~10 ms per call, a sixth of a 1024 x 1080p batch
+    struct BatchWorker {
+        canny_hip_ctx *sub = nullptr;
+        DevBuf d_in, d_out, d_out8;
+        PinBuf pin_in, pin_out;
+    };
+    std::vector<BatchWorker *> batch_pool;
 
     // device workspaces
     DevBuf tmp_f32;   // generic Gaussian row-pass plane
@@ -614,6 +649,17 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)finish_pending(ctx);
+    for (auto *w : ctx->batch_pool) {
+        w->d_in.release();
+        w->d_out.release();
+        w->d_out8.release();
+        w->pin_in.release();
+        w->pin_out.release();
+        canny_hip_ctx_destroy(w->sub);
+        delete w;
+    }
+    ctx->batch_pool.clear();
+    (void)hipSetDevice(ctx->device);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->tmp_f32.release();
@@ -660,6 +706,8 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
     else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
     else if (!std::strcmp(name, "overlap_hysteresis") && value <= 1) ctx->overlap_hysteresis = value;
+    else if (!std::strcmp(name, "tune_batch_workers") && value <= 16) ctx->batch_workers = value;
+    else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) ctx->batch_chunk_mb = value;
     else if (!std::strcmp(name, "stream_overlap") && value <= 1) {
         int rc = bind(ctx);
         if (rc || (rc = finish_pending(ctx))) return rc;
@@ -906,12 +954,6 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
     GaussTaps probe;
     if ((rc = make_taps(sigma, probe))) return rc;
     const size_t frame_px = npx(height, width, 1);
-    // ~64 MB of input per chunk keeps copies long enough to reach PCIe bandwidth
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, (64u << 20) / frame_px));
-    const int n_chunks = (n_frames + chunk - 1) / chunk;
-    const int n_workers = std::min(3, n_chunks);
-    std::vector<int> status(n_workers, CANNY_HIP_OK);
-    std::vector<std::string> errors(n_workers);
     const int device = ctx->device;
     // Buffers from canny_hip_host_alloc (or any hipHostMalloc / hipHostRegister'd memory) need no staging.
     auto is_pinned = [](const void *p) {
@@ -923,25 +965,42 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         return attr.type == hipMemoryTypeHost;
     };
     const bool in_pinned = is_pinned(imgs), out_pinned = is_pinned(edges);
-    auto worker = [&](int wid) {
-        canny_hip_ctx *sub = nullptr;
-        int st = canny_hip_ctx_create(&sub, device);
+    const bool all_pinned = in_pinned && out_pinned;
+    const size_t chunk_mb = ctx->batch_chunk_mb ? (size_t)ctx->batch_chunk_mb : (all_pinned ? 24u : 16u);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, (chunk_mb << 20) / frame_px));
+    const int n_chunks = (n_frames + chunk - 1) / chunk;
+    const int n_workers = std::min(ctx->batch_workers ? ctx->batch_workers : (all_pinned ? 2 : 4), n_chunks);
+    std::vector<int> status(n_workers, CANNY_HIP_OK);
+    std::vector<std::string> errors(n_workers);
+    while ((int)ctx->batch_pool.size() < n_workers) { // (sub-contexts are created here, on the caller's thread)
+        auto *w = new (std::nothrow) canny_hip_ctx::BatchWorker();
+        if (!w) return CANNY_HIP_ERR_RUNTIME;
+        int st = canny_hip_ctx_create(&w->sub, device);
         if (st) {
-            status[wid] = st;
+            delete w;
+            return st;
+        }
+        ctx->batch_pool.push_back(w);
+    }
+    auto worker = [&](int wid) {
+        canny_hip_ctx::BatchWorker &bw = *ctx->batch_pool[wid];
+        canny_hip_ctx *sub = bw.sub;
+        int st = CANNY_HIP_OK;
+        if (hipSetDevice(device) != hipSuccess) { // a new thread starts on device 0
+            status[wid] = CANNY_HIP_ERR_RUNTIME;
             return;
         }
-        unsigned char *pin_in = nullptr;
-        unsigned char *pin_out = nullptr;
-        void *d_in = nullptr, *d_out = nullptr, *d_out8 = nullptr;
         const size_t out_elem = out_u8 ? 1 : sizeof(short);
         const size_t in_bytes = frame_px * chunk, out_bytes = frame_px * chunk * out_elem;
         hipError_t e = hipSuccess;
         // pageable caller buffers are staged through pinned memory; pinned ones are DMA'd in place
-        if (!in_pinned) e = hipHostMalloc((void **)&pin_in, in_bytes);
-        if (e == hipSuccess && !out_pinned) e = hipHostMalloc((void **)&pin_out, out_bytes);
-        if (e == hipSuccess) e = hipMalloc(&d_in, in_bytes);
-        if (e == hipSuccess) e = hipMalloc(&d_out, frame_px * chunk * sizeof(short));
-        if (e == hipSuccess && out_u8) e = hipMalloc(&d_out8, out_bytes);
+        if (!in_pinned) e = bw.pin_in.ensure(in_bytes);
+        if (e == hipSuccess && !out_pinned) e = bw.pin_out.ensure(out_bytes);
+        if (e == hipSuccess) e = bw.d_in.ensure(in_bytes);
+        if (e == hipSuccess) e = bw.d_out.ensure(frame_px * chunk * sizeof(short));
+        if (e == hipSuccess && out_u8) e = bw.d_out8.ensure(out_bytes);
+        unsigned char *const pin_in = (unsigned char *)bw.pin_in.p, *const pin_out = (unsigned char *)bw.pin_out.p;
+        void *const d_in = bw.d_in.p, *const d_out = bw.d_out.p, *const d_out8 = bw.d_out8.p;
         if (e != hipSuccess) {
             status[wid] = fail(sub, e, "batch staging allocation");
         } else {
@@ -984,12 +1043,7 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             }
         }
         if (status[wid] != CANNY_HIP_OK) errors[wid] = sub->last_error;
-        if (pin_in) (void)hipHostFree(pin_in);
-        if (pin_out) (void)hipHostFree(pin_out);
-        if (d_in) (void)hipFree(d_in);
-        if (d_out) (void)hipFree(d_out);
-        if (d_out8) (void)hipFree(d_out8);
-        canny_hip_ctx_destroy(sub);
+        (void)st;
     };
     std::vector<std::thread> threads;
     for (int i = 1; i < n_workers; i++) threads.emplace_back(worker, i);

@@ -97,6 +97,9 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "overlap_hysteresis": 0 (default) / 1 -- canny() on 16 or more frames: the propagation sweeps of the first half
  *                    of the batch run on a second stream beside the Sobel+NMS kernel of the second half
  *                    (measured 1.5 % slower on 128 x 4K, kept for A/B)
+ *   "tune_batch_workers", "tune_batch_chunk_mb": canny_hip_canny_batch's host threads (streams) and megabytes of
+ *                    input per chunk; 0 (default) = automatic (2 x 24 MB between pinned buffers, 4 x 16 MB when a
+ *                    pageable buffer has to be staged)
  *   "stream_overlap": 0 (default) / 1 -- canny_hip_dev_canny_stream: the sweeps left in flight run on a second,
  *                    high-priority stream beside the next call's Gaussian instead of in order before it
  *                    (no gain on 128 x 4K batches, kept for A/B)

@@ -82,25 +82,28 @@ def main():
     frames = np.empty((N, H, W), np.uint8)
     for i in range(N):
         frames[i] = base[i % 16]
+    def best_of(fn, reps=3):  # every C3 figure: best of three calls
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best, r
+
     ctx.canny_batch(frames[:32], 1.0, 50, 150)  # warm-up (pinned staging, module load)
-    t0 = time.perf_counter()
-    edges = ctx.canny_batch(frames, 1.0, 50, 150)
-    t = time.perf_counter() - t0
+    t, edges = best_of(lambda: ctx.canny_batch(frames, 1.0, 50, 150))
     # the same batch from / into page-locked buffers (no staging memcpy on the host)
     pin_in = ctx.pinned_array((N, H, W), np.uint8)
     pin_out = ctx.pinned_array((N, H, W), np.int16)
     pin_in[:] = frames
     ctx.canny_batch(pin_in[:32], 1.0, 50, 150, out=pin_out[:32])
-    t0 = time.perf_counter()
-    ctx.canny_batch(pin_in, 1.0, 50, 150, out=pin_out)
-    tp = time.perf_counter() - t0
+    tp, _ = best_of(lambda: ctx.canny_batch(pin_in, 1.0, 50, 150, out=pin_out))
     same = bool(np.array_equal(pin_out, edges))
     # ... and with 8-bit edge maps coming back (canny_hip_canny_batch_u8): 4 instead of 6 bytes per pixel over PCIe
     pin_out8 = ctx.pinned_array((N, H, W), np.uint8)
     ctx.canny_batch(pin_in[:32], 1.0, 50, 150, out=pin_out8[:32], u8=True)
-    t0 = time.perf_counter()
-    ctx.canny_batch(pin_in, 1.0, 50, 150, out=pin_out8, u8=True)
-    tp8 = time.perf_counter() - t0
+    tp8, _ = best_of(lambda: ctx.canny_batch(pin_in, 1.0, 50, 150, out=pin_out8, u8=True))
     same8 = bool(np.array_equal(pin_out8[:64].astype(np.int16), edges[:64]))
     out["C3_batch_1080p_sigma1.0_u8_out"] = {
         "frames": N, "pinned_seconds": round(tp8, 4), "pinned_Mpix_s": round(N * H * W / tp8 / 1e6, 1),

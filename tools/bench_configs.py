@@ -3,7 +3,7 @@
 
   C2  single 3840x2160 frame, sigma 1.4   -- device-resident latency and host-to-host latency
   C3  batch of N x 1080p frames, sigma 1.0 -- canny_hip_canny_batch: host u8 in -> host s16 out, PCIe included,
-                                               H2D / kernels / D2H overlapped on three streams
+                                               H2D / kernels / D2H of alternating chunks overlapped on two streams
   C4  single 16384x16384 tile, sigma 2.0   -- device-resident and host-to-host
 
 Prints one JSON object.  `python tools/bench_configs.py [--c3-frames 1024]`"""

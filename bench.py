@@ -24,6 +24,11 @@ The JSON line also carries
                   0.25 B/px bit-planes out); `roofline_sobel_nms_s16` is the stage-API form SURVEY.md 8(d) prices at 4 B/px (s16 in,
                   s16 out), timed the same way on the same batch right after the timed region;
                   `roofline_other_kernels` prices the other kernels of the step the same way
+  host_to_host -- SURVEY.md 8(d) Metric 1 as the reference's GPU path pays it (src/cuda.cu:83-101: every frame
+                  crosses PCIe both ways): --h2h-frames 4K frames from pinned host memory through
+                  canny_hip_canny_batch (s16 maps, the reference's plane type) and canny_hip_canny_batch_u8, wall
+                  time including H2D and D2H, GB/s per direction against the PCIe 5 x16 link (63 GB/s spec), a single
+                  frame's latency, and the pageable-buffer rate.  `value` itself stays DEVICE-RESIDENT (`scope`).
   cpu_baseline -- the CPU oracle (a faithful single-thread restatement of the reference's utils.cpp;
                   the reference itself cannot be compiled here) timed on a bounded sample, rank 0, N=1
 torch is used only for device memory, the stream and torch.distributed.
@@ -39,6 +44,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PCIE_PEAK_GBS = 63.0   # PCIe Gen5 x16 per direction, spec (MI355X_MICROARCH.md, "Host link")
 
 
 def parse():
@@ -64,6 +70,9 @@ def parse():
                     help="untimed steps run for this long before the W warm-up steps: the device reaches its steady "
                          "clocks only after a few tenths of a second of load (3 warm-up steps = 7 ms: 2.46 ms per "
                          "step; 200: 2.40)")
+    ap.add_argument("--h2h-frames", type=int, default=128,
+                    help="frames per host-to-host batch (pinned host u8 in -> pinned host edge maps out); 0 skips it")
+    ap.add_argument("--h2h-reps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the pre-timing parity spot check")
     return ap.parse_args()
@@ -92,6 +101,66 @@ def cpu_baseline(frames, sigma, lo, hi, n_sample):
     }
 
 
+def host_to_host(capi, np, base_np, args, local_rank, rank, world, sync_max, check):
+    """SURVEY.md 8(d) Metric 1: host u8 frames in -> host edge maps out, H2D and D2H inside the timed region
+    (one-time setup -- context, pipelines, pinned buffers -- outside, as the metric defines it)."""
+    H, W, n = args.height, args.width, args.h2h_frames
+    px = n * H * W
+    res = {"frames_per_gpu": n, "height": H, "width": W, "sigma": args.sigma, "reps": args.h2h_reps,
+           "pcie_peak_GBps_per_direction": PCIE_PEAK_GBS,
+           "what": "canny_hip_canny_batch / _u8 on pinned host buffers: 3-stream chunk pipeline "
+                   "(upload | kernels | download), wall time per call, MAX over ranks"}
+    ctx = capi.Context(local_rank)
+    try:
+        src = ctx.pinned_array((n, H, W), np.uint8)
+        for i in range(n):
+            src[i] = base_np[i % len(base_np)]
+        outs = {"s16": ctx.pinned_array((n, H, W), np.int16), "u8": ctx.pinned_array((n, H, W), np.uint8)}
+        for name, out in outs.items():
+            u8 = name == "u8"
+            out[...] = 1
+            ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8)  # builds pipelines, staging
+            sync_max(0.0)
+            t0 = time.perf_counter()
+            for _ in range(args.h2h_reps):
+                ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8)
+            t = sync_max((time.perf_counter() - t0) / args.h2h_reps)
+            h2d, d2h = px / t / 1e9, px * out.itemsize / t / 1e9
+            res[name] = {"value": round(px * world / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_batch": round(t * 1e3, 3),
+                         "h2d_GBps_per_gpu": round(h2d, 2), "d2h_GBps_per_gpu": round(d2h, 2),
+                         "link_frac": round(max(h2d, d2h) / PCIE_PEAK_GBS, 4),
+                         "bytes_over_link_per_px": 1 + out.itemsize}
+            # one frame at a time (latency): pinned in, pinned out
+            one_in, one_out = src[:1], out[:1]
+            ctx.canny_batch(one_in, args.sigma, args.min_val, args.max_val, out=one_out, u8=u8)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ctx.canny_batch(one_in, args.sigma, args.min_val, args.max_val, out=one_out, u8=u8)
+            res[name]["single_frame_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
+        if check:
+            import oracle
+            ok = True
+            for i in (0, n - 1):
+                want = oracle.canny(base_np[i % len(base_np)], args.sigma, args.min_val, args.max_val)
+                ok = ok and bool(np.array_equal(outs["s16"][i], want)) and \
+                    bool(np.array_equal(outs["u8"][i], want.astype(np.uint8)))
+            res["parity_checked"] = ok
+            if not ok:
+                raise SystemExit("bench.py: host-to-host edge maps differ from the oracle -- refusing to report")
+        # pageable caller buffers (what a caller that never heard of pinned memory gets), s16, one call
+        pg_in = np.array(src[: max(1, n // 2)])
+        pg_out = np.empty(pg_in.shape, np.int16)
+        ctx.canny_batch(pg_in, args.sigma, args.min_val, args.max_val, out=pg_out)
+        t0 = time.perf_counter()
+        ctx.canny_batch(pg_in, args.sigma, args.min_val, args.max_val, out=pg_out)
+        t = sync_max(time.perf_counter() - t0)
+        res["s16_pageable"] = {"value": round(pg_in.size * world / t / 1e6, 1), "unit": "Mpixels/s",
+                               "frames_per_gpu": int(pg_in.shape[0]), "ms_per_batch": round(t * 1e3, 3)}
+    finally:
+        ctx.close()
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -113,6 +182,18 @@ def main():
 
     from canny_edge_amd import capi, sharding
     from canny_edge_amd.synth import synth_frame
+
+    # one process per GPU: run (and first-touch the pinned buffers) on the CPUs local to this rank's GPU
+    local_cpus = capi.device_local_cpus(local_rank)
+    if local_cpus and world > 1:
+        try:
+            cpus = set()
+            for part in local_cpus.split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+            os.sched_setaffinity(0, cpus & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+        except (OSError, ValueError):
+            pass
 
     H, W, F = args.height, args.width, args.frames
     distinct = min(16, F)
@@ -233,6 +314,18 @@ def main():
                  "unit": "Mpixels/s", "ms_per_step": round(el_plain / args.steps * 1e3, 4),
                  "what": "same workload through canny_hip_dev_canny (no overlap between consecutive steps)"}
 
+    # ---- host -> host (Metric 1 of SURVEY.md 8(d)) ------------------------------------------------------
+    def sync_max(t):
+        if world > 1:
+            dist.barrier()
+            return sharding.max_over_ranks(t, dev)
+        return t
+
+    h2h = None
+    if args.h2h_frames > 0:
+        h2h = host_to_host(capi, np, base_np, args, local_rank, rank, world, sync_max,
+                           check=(not args.no_check and rank == 0))
+
     # ---- roofline -------------------------------------------------------------------------------------
     # PMC-measured HBM bytes per launch (profiles/traffic_sobel_nms.json, made by tools/pmc_passes.sh +
     # tools/pmc_summary.py on this same workload); null when the file does not cover this shape.
@@ -241,7 +334,12 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("frames") == F and tj.get("height") == H and tj.get("width") == W:
+            # the PMC figure belongs to the kernel source it was measured on: stale after any edit of that file
+            import hashlib
+            src_sha = hashlib.sha256(open(os.path.join(ROOT, "canny_edge_amd", "csrc",
+                                                       "canny_sobel_nms_march.hip"), "rb").read()).hexdigest()
+            if tj.get("frames") == F and tj.get("height") == H and tj.get("width") == W and \
+                    tj.get("kernel_source_sha256") == src_sha:
                 measured = tj.get("kernels", {})
         except Exception:
             measured = {}
@@ -313,6 +411,8 @@ def main():
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32+s16",
+        "scope": "device-resident: frames already in HBM, edge maps left in HBM (the PCIe-inclusive figures are in "
+                 "host_to_host; they are never `value`)",
         "data": "synthetic",
         "config": {"workload": f"{F}x {W}x{H} gray frames per GPU per step, sigma={args.sigma}, "
                                f"thresholds {args.min_val}/{args.max_val}, inputs resident in HBM",
@@ -321,6 +421,7 @@ def main():
                              "Gaussian of step i+1; all K steps complete inside the timed region") if args.stream
                    else "canny_hip_dev_canny (blocking)",
                    "sharding": "independent frames per GPU, no collective"},
+        "host_to_host": h2h,
         "roofline": roofline,
         "roofline_sobel_nms_s16": roofline_s16,
         "roofline_other_kernels": per_kernel,
@@ -331,6 +432,10 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(base_np, args.sigma, args.min_val, args.max_val, args.cpu_frames)
+        out["vs_cpu_baseline"] = {"device_resident": round(value / out["cpu_baseline"]["value"], 1),
+                                  "host_to_host_s16": round(h2h["s16"]["value"] / out["cpu_baseline"]["value"], 1)
+                                  if h2h else None,
+                                  "note": "GPU / 1-thread CPU oracle; says nothing about kernel quality (roofline does)"}
     else:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -42,7 +42,8 @@ EXPORTS = (
     "canny_hip_dev_sobel", "canny_hip_dev_nms", "canny_hip_dev_sobel_nms", "canny_hip_dev_hysteresis",
     "canny_hip_dev_canny", "canny_hip_dev_canny_stream", "canny_hip_dev_canny_stream_flush", "canny_hip_profile_enable", "canny_hip_profile_reset", "canny_hip_profile_get",
     "canny_hip_selftest_mag_angle", "canny_hip_selftest_div", "canny_hip_selftest_div_fma",
-    "canny_hip_selftest_div_fma_table",
+    "canny_hip_selftest_div_fma_table", "canny_hip_canny_multi_gpu_u8", "canny_hip_multi_gpu_set_option",
+    "canny_hip_multi_gpu_release", "canny_hip_device_local_cpus", "canny_hip_selftest_cpulist_count",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -98,6 +99,11 @@ def load() -> C.CDLL:
         "canny_hip_canny_batch_u8": ([p, p, i, f, i, i, i, i, p], i),
         "canny_hip_dev_canny_u8": ([p, p, f, i, i, i, i, i, p], i),
         "canny_hip_canny_multi_gpu": ([p, i, f, i, i, i, i, p, i], i),
+        "canny_hip_canny_multi_gpu_u8": ([p, i, f, i, i, i, i, p, i], i),
+        "canny_hip_multi_gpu_set_option": ([C.c_char_p, i], i),
+        "canny_hip_multi_gpu_release": ([], i),
+        "canny_hip_device_local_cpus": ([i, C.c_char_p, i], i),
+        "canny_hip_selftest_cpulist_count": ([C.c_char_p], i),
         "canny_hip_shard_range": ([i, i, i, ip, ip], i),
         "canny_hip_dev_gaussian": ([p, p, f, i, i, i, p], i),
         "canny_hip_dev_xy_gradient": ([p, p, i, i, i, p, p], i),
@@ -392,17 +398,44 @@ class Context:
                                                    C.c_void_p(d_edges)), "dev_canny_u8")
 
 
-def canny_multi_gpu(imgs, sigma: float, min_val: int, max_val: int, n_devices: int = 0) -> np.ndarray:
-    """Shard [n_frames, H, W] by contiguous ranges over the node's GPUs (one host thread per GPU)."""
+def canny_multi_gpu(imgs, sigma: float, min_val: int, max_val: int, n_devices: int = 0, u8: bool = False,
+                    out: Optional[np.ndarray] = None) -> np.ndarray:
+    """Shard [n_frames, H, W] by contiguous ranges over the node's GPUs (one host thread per GPU, each running
+    the batch pipeline; per-device contexts are cached until multi_gpu_release())."""
     a = np.ascontiguousarray(imgs, dtype=np.uint8)
     if a.ndim != 3:
         raise ValueError("expected uint8 [n_frames, H, W]")
-    out = np.empty(a.shape, np.int16)
-    st = load().canny_hip_canny_multi_gpu(_hp(a), a.shape[0], sigma, min_val, max_val, a.shape[1], a.shape[2],
-                                          _hp(out), n_devices)
+    dtype = np.uint8 if u8 else np.int16
+    if out is None:
+        out = np.empty(a.shape, dtype)
+    elif out.shape != a.shape or out.dtype != dtype or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of the input's shape")
+    fn = load().canny_hip_canny_multi_gpu_u8 if u8 else load().canny_hip_canny_multi_gpu
+    st = fn(_hp(a), a.shape[0], sigma, min_val, max_val, a.shape[1], a.shape[2], _hp(out), n_devices)
     if st:
         raise CannyHipError(st, "canny_multi_gpu")
     return out
+
+
+def multi_gpu_set_option(name: str, value: int):
+    st = load().canny_hip_multi_gpu_set_option(name.encode(), value)
+    if st:
+        raise CannyHipError(st, f"multi_gpu_set_option({name})")
+
+
+def multi_gpu_release():
+    load().canny_hip_multi_gpu_release()
+
+
+def device_local_cpus(device: int) -> Optional[str]:
+    """sysfs CPU list local to a GPU ("0-31,128-159"), None if the platform does not say."""
+    buf = C.create_string_buffer(4096)
+    st = load().canny_hip_device_local_cpus(device, buf, len(buf))
+    return buf.value.decode() if st == 0 else None
+
+
+def cpulist_count(text: str) -> int:
+    return load().canny_hip_selftest_cpulist_count(text.encode())
 
 
 # ---- the reference's stage names (src/utils.h:8-22) on a process-wide default context -------------

@@ -9,13 +9,17 @@
 #include "canny_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cctype>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -109,20 +113,16 @@ struct canny_hip_ctx {
     int sobel_nms_path = 0;  // 0 auto, 1 LDS tile, 2 march
     int tune_sobel_seg = 0;  // A/B knob of the marching Sobel+NMS kernel: rows per segment, 0 = automatic
     int fuse_classify = 1;   // canny(): Sobel+NMS emits the hysteresis bit-planes directly when it can
-    // canny_hip_canny_batch: host threads (= streams) that each take every n-th chunk, and megabytes of input per
-    // chunk.  0 = automatic: 2 x 24 MB between pinned buffers (1024 x 1080p: 93 ms against 108 ms with 3 x 64 MB;
-    // a third stream only makes the two DMA directions wait for each other), 4 x 16 MB when a pageable buffer has
-    // to be staged by the worker threads (183 ms against 280 ms with 3 x 64 MB).
+    // canny_hip_canny_batch: number of pipelines (host threads, each with an H2D, a compute and a D2H stream and a
+    // ring of chunk slots) that each take every n-th chunk, and the chunk size (megabytes of input, or frames).
+    // 0 = automatic, see canny_batch_impl.
     int batch_workers = 0;
     int batch_chunk_mb = 0;
-    // the batch pipeline's workers live as long as the context: creating a sub-context with its stream and
-    // allocating its staging cost ~10 ms per call, a sixth of a 1024 x 1080p batch
-    struct BatchWorker {
-        canny_hip_ctx *sub = nullptr;
-        DevBuf d_in, d_out, d_out8;
-        PinBuf pin_in, pin_out;
-    };
-    std::vector<BatchWorker *> batch_pool;
+    int batch_chunk_frames = 0;
+    // the pipelines live as long as the context: creating a sub-context with its streams and allocating its
+    // staging costs ~10 ms per call, a sixth of a 1024 x 1080p batch
+    struct BatchPipe;
+    std::vector<BatchPipe *> batch_pool;
 
     // device workspaces
     DevBuf tmp_f32;   // generic Gaussian row-pass plane
@@ -155,6 +155,26 @@ struct canny_hip_ctx {
     std::vector<EventPair> pool;
     double total_ms[CANNY_HIP_STAGE_COUNT] = {0};
     long launches[CANNY_HIP_STAGE_COUNT] = {0};
+};
+
+// One batch pipeline: three streams and a ring of chunk slots.  Chunk j of the pipeline lives in slot j % kSlots:
+//   s_h2d:    host -> d_in                       (ev_h2d)
+//   compute:  d_in -> d_out [-> d_out8]           (ev_comp; the sub-context's stream, waits for ev_h2d)
+//   s_d2h:    d_out / d_out8 -> host              (ev_d2h; waits for ev_comp)
+// so that the upload of chunk j+1, the kernels of chunk j and the download of chunk j-1 are in flight together and
+// neither DMA engine waits for a host thread.  Pageable caller buffers go through the slot's pinned staging.
+struct canny_hip_ctx::BatchPipe {
+    static constexpr int kSlots = 3;
+    canny_hip_ctx *sub = nullptr;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    struct Slot {
+        DevBuf d_in, d_out, d_out8;
+        PinBuf pin_in, pin_out;
+        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_d2h = nullptr;
+        bool d2h_issued = false;      // ev_d2h has been recorded during the current call
+        void *retire_dst = nullptr;   // pageable output: where pin_out goes once ev_d2h has fired
+        size_t retire_bytes = 0;
+    } slot[kSlots];
 };
 
 namespace {
@@ -242,6 +262,12 @@ int check_dims(int height, int width, int n_frames)
     if (n_frames > 65535) return CANNY_HIP_ERR_UNSUPPORTED;
     return CANNY_HIP_OK;
 }
+
+// Reached pixels are overwritten with EDGE = 255 while the reference's scan is still running (src/utils.cpp:327-334,
+// 367).  With min_val > 255 such a pixel then fails the scan's own `< minVal` test when the scan reaches it and
+// is zeroed again -- unless the scan has already passed it: the result depends on the scan order, which the
+// parallel formulation does not have.  (If max_val > 255 as well everything ends as 0 either way.)
+bool hysteresis_order_dependent(int min_val, int max_val) { return min_val > 255 && max_val <= 255; }
 
 size_t npx(int height, int width, int n_frames) { return (size_t)height * (size_t)width * (size_t)n_frames; }
 
@@ -406,6 +432,7 @@ int finish_pending(canny_hip_ctx *ctx);
 
 int dev_hysteresis(canny_hip_ctx *ctx, short *d_cand, int h, int w, int n, int lo, int hi)
 {
+    if (hysteresis_order_dependent(lo, hi)) return CANNY_HIP_ERR_DOMAIN;
     HystGeom g = make_hyst_geom(h, w, n);
     int rc = finish_pending(ctx); // a streamed call's sweeps own the planes until they are done
     if (rc || (rc = ensure_hyst(ctx, g))) return rc;
@@ -436,6 +463,7 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
               short *d_edges)
 {
     if (h < 2 || w < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    if (hysteresis_order_dependent(lo, hi)) return CANNY_HIP_ERR_DOMAIN;
     int rc = finish_pending(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, ctx->smoothed.ensure(npx(h, w, n) * sizeof(short)));
@@ -538,6 +566,7 @@ int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma
                      short *d_edges)
 {
     if (h < 2 || w < 2) return CANNY_HIP_ERR_UNSUPPORTED;
+    if (hysteresis_order_dependent(lo, hi)) return CANNY_HIP_ERR_DOMAIN;
     if (!(ctx->fuse_classify && ctx->sobel_nms_path != 1 && sobel_nms_classify_supported(h, w, lo))) {
         int rc = finish_pending(ctx); // shapes the fused kernel does not take: plain call, nothing left in flight
         return rc ? rc : dev_canny(ctx, d_img, sigma, lo, hi, h, w, n, d_edges);
@@ -580,6 +609,49 @@ int d2h_sync(canny_hip_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+void destroy_batch_pipe(canny_hip_ctx::BatchPipe *w)
+{
+    if (!w) return;
+    if (w->sub) (void)hipSetDevice(w->sub->device);
+    if (w->s_h2d) (void)hipStreamSynchronize(w->s_h2d);
+    if (w->s_d2h) (void)hipStreamSynchronize(w->s_d2h);
+    for (auto &sl : w->slot) {
+        sl.d_in.release();
+        sl.d_out.release();
+        sl.d_out8.release();
+        sl.pin_in.release();
+        sl.pin_out.release();
+        for (hipEvent_t e : {sl.ev_h2d, sl.ev_comp, sl.ev_d2h})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (w->s_h2d) (void)hipStreamDestroy(w->s_h2d);
+    if (w->s_d2h) (void)hipStreamDestroy(w->s_d2h);
+    canny_hip_ctx_destroy(w->sub);
+    delete w;
+}
+
+int create_batch_pipe(canny_hip_ctx *ctx, canny_hip_ctx::BatchPipe **out)
+{
+    auto *w = new (std::nothrow) canny_hip_ctx::BatchPipe();
+    if (!w) return CANNY_HIP_ERR_RUNTIME;
+    int st = canny_hip_ctx_create(&w->sub, ctx->device);
+    hipError_t e = hipSuccess;
+    if (!st) {
+        e = hipStreamCreateWithFlags(&w->s_h2d, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->s_d2h, hipStreamNonBlocking);
+        for (auto &sl : w->slot)
+            for (hipEvent_t *ev : {&sl.ev_h2d, &sl.ev_comp, &sl.ev_d2h})
+                if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (e != hipSuccess) st = fail(ctx, e, "batch pipeline streams/events");
+    }
+    if (st) {
+        destroy_batch_pipe(w);
+        return st;
+    }
+    *out = w;
     return CANNY_HIP_OK;
 }
 
@@ -649,15 +721,7 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)finish_pending(ctx);
-    for (auto *w : ctx->batch_pool) {
-        w->d_in.release();
-        w->d_out.release();
-        w->d_out8.release();
-        w->pin_in.release();
-        w->pin_out.release();
-        canny_hip_ctx_destroy(w->sub);
-        delete w;
-    }
+    for (auto *w : ctx->batch_pool) destroy_batch_pipe(w);
     ctx->batch_pool.clear();
     (void)hipSetDevice(ctx->device);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
@@ -708,6 +772,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "overlap_hysteresis") && value <= 1) ctx->overlap_hysteresis = value;
     else if (!std::strcmp(name, "tune_batch_workers") && value <= 16) ctx->batch_workers = value;
     else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) ctx->batch_chunk_mb = value;
+    else if (!std::strcmp(name, "tune_batch_chunk_frames") && value <= 65535) ctx->batch_chunk_frames = value;
     else if (!std::strcmp(name, "stream_overlap") && value <= 1) {
         int rc = bind(ctx);
         if (rc || (rc = finish_pending(ctx))) return rc;
@@ -892,7 +957,11 @@ int canny_hip_find_edge_pixels(canny_hip_ctx *ctx, short *edge_candidates, unsig
     size_t n = npx(height, width, 1);
     if (start < 0 || (size_t)start >= n) return CANNY_HIP_ERR_INVALID;
     if (visited[start]) return CANNY_HIP_OK; // src/utils.cpp:361
+    // min_val > EDGE: a popped pixel (now 255) fails the `>= minVal` test of its neighbours' checks, which changes
+    // the reference's visited bookkeeping of the start pixel with the pop order
+    if (min_val > 255) return CANNY_HIP_ERR_DOMAIN;
     HystGeom g = make_hyst_geom(height, width, 1);
+    if ((rc = finish_pending(ctx))) return rc; // a streamed call's sweeps own the planes until they are done
     if ((rc = ensure_hyst(ctx, g))) return rc;
     if ((rc = h2d(ctx, ctx->io[0], edge_candidates, n * 2))) return rc;
     if ((rc = h2d(ctx, ctx->io[1], visited, n))) return rc;
@@ -939,18 +1008,28 @@ int canny_hip_shard_range(int n_frames, int rank, int world, int *begin, int *en
     return CANNY_HIP_OK;
 }
 
-// Stream-overlapped batch: the frames are cut into chunks; up to three worker threads, each with its
-// own stream, device workspace and pinned staging, take chunks round-robin so that the H2D copy of
-// one chunk, the kernels of another and the D2H copy of a third are in flight together.
+// Stream-overlapped batch (BASELINE config 3).  The frames are cut into chunks; every pipeline (BatchPipe: one host
+// thread, an upload, a compute and a download stream, three chunk slots) takes every n-th chunk and runs
+//     upload(j+1) | kernels(j) | download(j-1)
+// concurrently, chained by events only: the host thread never waits for a copy, it only blocks where
+// canny() itself does (the hysteresis convergence poll at the end of a chunk's kernels), by which time the next
+// chunk's upload has long been queued.  On an MI355X the kernels run at ~450 Gpix/s and a PCIe 5 x16 link moves
+// ~56 GB/s per direction (48 + 48 GB/s with both directions busy): the link is the bound, and the pipeline's job is
+// to keep both DMA engines busy all the time.
+//   pinned caller buffers (canny_hip_host_alloc, hipHostMalloc, hipHostRegister): DMA'd in place, one pipeline;
+//   pageable caller buffers: staged through the slot's pinned buffers by the pipeline's own thread (memcpy), so
+//   several pipelines run side by side to get enough copy bandwidth.
 // out_u8: `edges` is an unsigned char plane per frame (0 / 255) instead of a short plane.
 static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
                             int max_val, int height, int width, void *edges, bool out_u8)
 {
+    using Pipe = canny_hip_ctx::BatchPipe;
     int rc = bind(ctx);
     if (rc) return rc;
     if (!imgs || !edges) return CANNY_HIP_ERR_INVALID;
     if ((rc = check_dims(height, width, 1))) return rc;
     if (n_frames < 1) return CANNY_HIP_ERR_INVALID;
+    if (height < 2 || width < 2) return CANNY_HIP_ERR_UNSUPPORTED;
     GaussTaps probe;
     if ((rc = make_taps(sigma, probe))) return rc;
     const size_t frame_px = npx(height, width, 1);
@@ -966,84 +1045,125 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
     };
     const bool in_pinned = is_pinned(imgs), out_pinned = is_pinned(edges);
     const bool all_pinned = in_pinned && out_pinned;
-    const size_t chunk_mb = ctx->batch_chunk_mb ? (size_t)ctx->batch_chunk_mb : (all_pinned ? 24u : 16u);
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, (chunk_mb << 20) / frame_px));
+    // chunk: 24 MB of input between pinned buffers, 16 MB when a pageable side has to be staged; never more than
+    // the 65535 frames a launch takes
+    size_t chunk_frames = ctx->batch_chunk_frames
+                              ? (size_t)ctx->batch_chunk_frames
+                              : ((size_t)(ctx->batch_chunk_mb ? ctx->batch_chunk_mb : (all_pinned ? 24 : 16)) << 20) / frame_px;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, 65535), chunk_frames));
     const int n_chunks = (n_frames + chunk - 1) / chunk;
-    const int n_workers = std::min(ctx->batch_workers ? ctx->batch_workers : (all_pinned ? 2 : 4), n_chunks);
+    const int n_workers = std::min(ctx->batch_workers ? ctx->batch_workers : (all_pinned ? 1 : 4), n_chunks);
     std::vector<int> status(n_workers, CANNY_HIP_OK);
     std::vector<std::string> errors(n_workers);
     while ((int)ctx->batch_pool.size() < n_workers) { // (sub-contexts are created here, on the caller's thread)
-        auto *w = new (std::nothrow) canny_hip_ctx::BatchWorker();
-        if (!w) return CANNY_HIP_ERR_RUNTIME;
-        int st = canny_hip_ctx_create(&w->sub, device);
-        if (st) {
-            delete w;
-            return st;
-        }
+        Pipe *w = nullptr;
+        if ((rc = create_batch_pipe(ctx, &w))) return rc;
         ctx->batch_pool.push_back(w);
     }
+    const size_t out_elem = out_u8 ? 1 : sizeof(short);
+
     auto worker = [&](int wid) {
-        canny_hip_ctx::BatchWorker &bw = *ctx->batch_pool[wid];
-        canny_hip_ctx *sub = bw.sub;
-        int st = CANNY_HIP_OK;
+        Pipe &P = *ctx->batch_pool[wid];
+        canny_hip_ctx *sub = P.sub;
+        int &st = status[wid];
         if (hipSetDevice(device) != hipSuccess) { // a new thread starts on device 0
-            status[wid] = CANNY_HIP_ERR_RUNTIME;
+            st = CANNY_HIP_ERR_RUNTIME;
             return;
         }
-        const size_t out_elem = out_u8 ? 1 : sizeof(short);
+        const int my_chunks = (n_chunks - wid + n_workers - 1) / n_workers;
         const size_t in_bytes = frame_px * chunk, out_bytes = frame_px * chunk * out_elem;
         hipError_t e = hipSuccess;
-        // pageable caller buffers are staged through pinned memory; pinned ones are DMA'd in place
-        if (!in_pinned) e = bw.pin_in.ensure(in_bytes);
-        if (e == hipSuccess && !out_pinned) e = bw.pin_out.ensure(out_bytes);
-        if (e == hipSuccess) e = bw.d_in.ensure(in_bytes);
-        if (e == hipSuccess) e = bw.d_out.ensure(frame_px * chunk * sizeof(short));
-        if (e == hipSuccess && out_u8) e = bw.d_out8.ensure(out_bytes);
-        unsigned char *const pin_in = (unsigned char *)bw.pin_in.p, *const pin_out = (unsigned char *)bw.pin_out.p;
-        void *const d_in = bw.d_in.p, *const d_out = bw.d_out.p, *const d_out8 = bw.d_out8.p;
-        if (e != hipSuccess) {
-            status[wid] = fail(sub, e, "batch staging allocation");
-        } else {
-            for (int c = wid; c < n_chunks && status[wid] == CANNY_HIP_OK; c += n_workers) {
-                int f0 = c * chunk, nf = std::min(chunk, n_frames - f0);
-                const unsigned char *src = imgs + (size_t)f0 * frame_px;
-                if (!in_pinned) {
-                    std::memcpy(pin_in, src, frame_px * nf);
-                    src = pin_in;
-                }
-                e = hipMemcpyAsync(d_in, src, frame_px * nf, hipMemcpyHostToDevice, sub->stream);
-                if (e != hipSuccess) {
-                    status[wid] = fail(sub, e, "batch H2D");
-                    break;
-                }
-                st = dev_canny(sub, (const unsigned char *)d_in, sigma, min_val, max_val, height, width, nf,
-                               (short *)d_out);
-                if (st) {
-                    status[wid] = st;
-                    break;
-                }
-                const void *d_res = d_out;
-                if (out_u8) { // narrow on the device: the D2H copy is what this variant is for
-                    e = launch_edges_to_u8((const int16_t *)d_out, (uint8_t *)d_out8, frame_px * nf, sub->stream);
-                    if (e != hipSuccess) {
-                        status[wid] = fail(sub, e, "batch u8 narrowing");
-                        break;
-                    }
-                    d_res = d_out8;
-                }
-                unsigned char *dst = (unsigned char *)edges + (size_t)f0 * frame_px * out_elem;
-                e = hipMemcpyAsync(out_pinned ? dst : pin_out, d_res, frame_px * nf * out_elem, hipMemcpyDeviceToHost,
-                                   sub->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(sub->stream);
-                if (e != hipSuccess) {
-                    status[wid] = fail(sub, e, "batch D2H");
-                    break;
-                }
-                if (!out_pinned) std::memcpy(dst, pin_out, frame_px * nf * out_elem);
-            }
+        for (int k = 0; k < std::min(my_chunks, (int)Pipe::kSlots) && e == hipSuccess; k++) {
+            Pipe::Slot &S = P.slot[k];
+            S.d2h_issued = false;
+            S.retire_dst = nullptr;
+            // pageable caller buffers are staged through pinned memory; pinned ones are DMA'd in place
+            if (!in_pinned) e = S.pin_in.ensure(in_bytes);
+            if (e == hipSuccess && !out_pinned) e = S.pin_out.ensure(out_bytes);
+            if (e == hipSuccess) e = S.d_in.ensure(in_bytes);
+            if (e == hipSuccess) e = S.d_out.ensure(frame_px * chunk * sizeof(short));
+            if (e == hipSuccess && out_u8) e = S.d_out8.ensure(out_bytes);
         }
-        if (status[wid] != CANNY_HIP_OK) errors[wid] = sub->last_error;
-        (void)st;
+        if (e != hipSuccess) {
+            st = fail(sub, e, "batch staging allocation");
+            errors[wid] = sub->last_error;
+            return;
+        }
+        auto chunk_range = [&](int j, int &f0, int &nf) {
+            const int c = wid + j * n_workers;
+            f0 = c * chunk;
+            nf = std::min(chunk, n_frames - f0);
+        };
+        // host -> d_in of chunk j.  The slot's previous user (chunk j - kSlots) has finished its kernels: the host
+        // blocked in dev_canny for it, so d_in and pin_in are free.
+        auto upload = [&](int j) -> hipError_t {
+            Pipe::Slot &S = P.slot[j % Pipe::kSlots];
+            int f0, nf;
+            chunk_range(j, f0, nf);
+            const unsigned char *src = imgs + (size_t)f0 * frame_px;
+            if (!in_pinned) {
+                std::memcpy(S.pin_in.p, src, frame_px * nf);
+                src = (const unsigned char *)S.pin_in.p;
+            }
+            hipError_t err = hipMemcpyAsync(S.d_in.p, src, frame_px * nf, hipMemcpyHostToDevice, P.s_h2d);
+            if (err == hipSuccess) err = hipEventRecord(S.ev_h2d, P.s_h2d);
+            return err;
+        };
+        // the staged output of chunk j reaches the caller's pageable buffer
+        auto retire = [&](int j) -> hipError_t {
+            Pipe::Slot &S = P.slot[j % Pipe::kSlots];
+            if (!S.retire_dst) return hipSuccess;
+            hipError_t err = hipEventSynchronize(S.ev_d2h);
+            if (err == hipSuccess) std::memcpy(S.retire_dst, S.pin_out.p, S.retire_bytes);
+            S.retire_dst = nullptr;
+            return err;
+        };
+        const char *where = "batch H2D";
+        e = upload(0);
+        for (int j = 0; j < my_chunks && e == hipSuccess && st == CANNY_HIP_OK; j++) {
+            Pipe::Slot &S = P.slot[j % Pipe::kSlots];
+            int f0, nf;
+            chunk_range(j, f0, nf);
+            if (j + 1 < my_chunks && (e = upload(j + 1)) != hipSuccess) break;
+            // kernels of chunk j: behind its upload, and behind the download that last read this slot's outputs
+            where = "batch compute";
+            if ((e = hipStreamWaitEvent(sub->stream, S.ev_h2d, 0)) != hipSuccess) break;
+            if (S.d2h_issued && (e = hipStreamWaitEvent(sub->stream, S.ev_d2h, 0)) != hipSuccess) break;
+            st = dev_canny(sub, (const unsigned char *)S.d_in.p, sigma, min_val, max_val, height, width, nf,
+                           (short *)S.d_out.p);
+            if (st) break;
+            const void *d_res = S.d_out.p;
+            if (out_u8) { // narrow on the device: the D2H copy is what this variant is for
+                if ((e = launch_edges_to_u8((const int16_t *)S.d_out.p, (uint8_t *)S.d_out8.p, frame_px * nf,
+                                            sub->stream)) != hipSuccess)
+                    break;
+                d_res = S.d_out8.p;
+            }
+            if ((e = hipEventRecord(S.ev_comp, sub->stream)) != hipSuccess) break;
+            // download of chunk j (pin_out of this slot was retired kSlots - 1 iterations ago)
+            where = "batch D2H";
+            unsigned char *dst = (unsigned char *)edges + (size_t)f0 * frame_px * out_elem;
+            const size_t bytes = frame_px * nf * out_elem;
+            if ((e = hipStreamWaitEvent(P.s_d2h, S.ev_comp, 0)) != hipSuccess) break;
+            if ((e = hipMemcpyAsync(out_pinned ? (void *)dst : S.pin_out.p, d_res, bytes, hipMemcpyDeviceToHost,
+                                    P.s_d2h)) != hipSuccess)
+                break;
+            if ((e = hipEventRecord(S.ev_d2h, P.s_d2h)) != hipSuccess) break;
+            S.d2h_issued = true;
+            if (!out_pinned) {
+                S.retire_dst = dst;
+                S.retire_bytes = bytes;
+            }
+            if (j > 0 && (e = retire(j - 1)) != hipSuccess) break;
+        }
+        if (e == hipSuccess && st == CANNY_HIP_OK && my_chunks > 0) e = retire(my_chunks - 1);
+        // nothing of this call may still be in flight when it returns (also after an error: the slots are reused)
+        hipError_t e2 = hipStreamSynchronize(P.s_h2d);
+        hipError_t e3 = hipStreamSynchronize(sub->stream);
+        hipError_t e4 = hipStreamSynchronize(P.s_d2h);
+        if (e == hipSuccess) e = e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4);
+        if (e != hipSuccess && st == CANNY_HIP_OK) st = fail(sub, e, where);
+        if (st != CANNY_HIP_OK) errors[wid] = sub->last_error;
     };
     std::vector<std::thread> threads;
     for (int i = 1; i < n_workers; i++) threads.emplace_back(worker, i);
@@ -1069,36 +1189,189 @@ int canny_hip_canny_batch_u8(canny_hip_ctx *ctx, const unsigned char *imgs, int 
     return canny_batch_impl(ctx, imgs, n_frames, sigma, min_val, max_val, height, width, edges, true);
 }
 
-int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
-                              int height, int width, short *edges, int n_devices)
+// ---- multi-GPU sharder (BASELINE config 5) -----------------------------------------------------------
+// One context per shard, kept between calls (a context with its pipelines, streams and staging costs ~10-20 ms to
+// build); one host thread per shard per call, bound to the CPUs that are local to the shard's GPU.
+namespace {
+struct MultiGpuState {
+    std::mutex mu;
+    std::vector<canny_hip_ctx *> shard_ctx; // index = shard
+    std::vector<int> shard_dev;
+    int batch_workers = 0, batch_chunk_mb = 0, batch_chunk_frames = 0;
+    int allow_device_reuse = 0; // shards beyond the device count wrap around (testing the sharder on a small box)
+    int numa_affinity = 1;
+};
+MultiGpuState g_mgpu;
+
+// "0-3,8,10-11" -> cpu_set_t; returns the number of CPUs set (0 on a malformed list)
+int parse_cpulist(const char *text, cpu_set_t *set)
+{
+    CPU_ZERO(set);
+    int count = 0;
+    const char *p = text;
+    while (*p) {
+        while (*p == ' ' || *p == ',' || *p == '\n' || *p == '\t') p++;
+        if (!*p) break;
+        char *end = nullptr;
+        long a = std::strtol(p, &end, 10);
+        if (end == p || a < 0) return 0;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            p++;
+            b = std::strtol(p, &end, 10);
+            if (end == p || b < a) return 0;
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) {
+            CPU_SET((int)c, set);
+            count++;
+        }
+    }
+    return count;
+}
+
+// CPUs local to a GPU, from sysfs (/sys/bus/pci/devices/<bdf>/local_cpulist, e.g. "0-31,128-159")
+bool device_local_cpus(int device, cpu_set_t *set)
+{
+    char bdf[32] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    for (char *c = bdf; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    FILE *f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    const bool got = std::fgets(line, sizeof line, f) != nullptr;
+    std::fclose(f);
+    if (!got) return false;
+    return parse_cpulist(line, set) > 0;
+}
+} // namespace
+
+static int multi_gpu_impl(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val, int height,
+                          int width, void *edges, int n_devices, bool out_u8)
 {
     if (!imgs || !edges || n_frames < 1) return CANNY_HIP_ERR_INVALID;
     int avail = 0;
     int rc = canny_hip_device_count(&avail);
     if (rc) return rc;
     if (avail < 1) return CANNY_HIP_ERR_NO_DEVICE;
-    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
-    n_devices = std::min(n_devices, n_frames);
-    std::vector<int> status(n_devices, CANNY_HIP_OK);
+    std::lock_guard<std::mutex> lock(g_mgpu.mu); // one sharded call at a time per process
+    if (n_devices <= 0) n_devices = avail;
+    if (n_devices > avail && !g_mgpu.allow_device_reuse) n_devices = avail;
+    if (n_devices > 64) return CANNY_HIP_ERR_INVALID;
+    const int n_shards = n_devices;
     const size_t frame_px = npx(height, width, 1);
-    auto worker = [&](int dev) {
+    const size_t out_elem = out_u8 ? 1 : sizeof(short);
+    // contexts are created here, on the caller's thread, and kept for the next call
+    while ((int)g_mgpu.shard_ctx.size() < n_shards) {
+        const int shard = (int)g_mgpu.shard_ctx.size();
+        canny_hip_ctx *c = nullptr;
+        if ((rc = canny_hip_ctx_create(&c, shard % avail))) return rc;
+        g_mgpu.shard_ctx.push_back(c);
+        g_mgpu.shard_dev.push_back(shard % avail);
+    }
+    std::vector<int> status(n_shards, CANNY_HIP_OK);
+    auto worker = [&](int shard, bool own_thread) {
         int b = 0, e = 0;
-        canny_hip_shard_range(n_frames, dev, n_devices, &b, &e);
-        if (e <= b) return;
-        canny_hip_ctx *ctx = nullptr;
-        int st = canny_hip_ctx_create(&ctx, dev);
-        if (!st)
-            st = canny_hip_canny_batch(ctx, imgs + (size_t)b * frame_px, e - b, sigma, min_val, max_val, height, width,
-                                       edges + (size_t)b * frame_px);
-        status[dev] = st;
-        canny_hip_ctx_destroy(ctx);
+        canny_hip_shard_range(n_frames, shard, n_shards, &b, &e);
+        if (e <= b) return; // more shards than frames
+        canny_hip_ctx *ctx = g_mgpu.shard_ctx[shard];
+        ctx->batch_workers = g_mgpu.batch_workers;
+        ctx->batch_chunk_mb = g_mgpu.batch_chunk_mb;
+        ctx->batch_chunk_frames = g_mgpu.batch_chunk_frames;
+        // run next to the GPU: this thread and the pipeline threads it starts inherit the mask.  The caller's own
+        // thread (shard 0) gets its mask back afterwards.
+        cpu_set_t local, saved;
+        bool restore = false;
+        if (g_mgpu.numa_affinity && device_local_cpus(g_mgpu.shard_dev[shard], &local)) {
+            if (!own_thread) restore = sched_getaffinity(0, sizeof saved, &saved) == 0;
+            if (own_thread || restore) (void)sched_setaffinity(0, sizeof local, &local); // best effort
+        }
+        status[shard] = canny_batch_impl(ctx, imgs + (size_t)b * frame_px, e - b, sigma, min_val, max_val, height,
+                                         width, (unsigned char *)edges + (size_t)b * frame_px * out_elem, out_u8);
+        if (restore) (void)sched_setaffinity(0, sizeof saved, &saved);
     };
     std::vector<std::thread> threads;
-    for (int d = 1; d < n_devices; d++) threads.emplace_back(worker, d);
-    worker(0);
+    for (int d = 1; d < n_shards; d++) threads.emplace_back(worker, d, true);
+    worker(0, false);
     for (auto &t : threads) t.join();
     for (int s : status)
         if (s) return s;
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
+                              int height, int width, short *edges, int n_devices)
+{
+    return multi_gpu_impl(imgs, n_frames, sigma, min_val, max_val, height, width, edges, n_devices, false);
+}
+
+int canny_hip_canny_multi_gpu_u8(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
+                                 int height, int width, unsigned char *edges, int n_devices)
+{
+    return multi_gpu_impl(imgs, n_frames, sigma, min_val, max_val, height, width, edges, n_devices, true);
+}
+
+int canny_hip_multi_gpu_set_option(const char *name, int value)
+{
+    if (!name || value < 0) return CANNY_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(g_mgpu.mu);
+    if (!std::strcmp(name, "tune_batch_workers") && value <= 16) g_mgpu.batch_workers = value;
+    else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) g_mgpu.batch_chunk_mb = value;
+    else if (!std::strcmp(name, "tune_batch_chunk_frames") && value <= 65535) g_mgpu.batch_chunk_frames = value;
+    else if (!std::strcmp(name, "allow_device_reuse") && value <= 1) g_mgpu.allow_device_reuse = value;
+    else if (!std::strcmp(name, "numa_affinity") && value <= 1) g_mgpu.numa_affinity = value;
+    else return CANNY_HIP_ERR_INVALID;
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_multi_gpu_release(void)
+{
+    std::lock_guard<std::mutex> lock(g_mgpu.mu);
+    for (canny_hip_ctx *c : g_mgpu.shard_ctx) canny_hip_ctx_destroy(c);
+    g_mgpu.shard_ctx.clear();
+    g_mgpu.shard_dev.clear();
+    return CANNY_HIP_OK;
+}
+
+// Number of CPUs in a sysfs-style list ("0-3,8,10-11" -> 7), 0 if malformed: the parser behind the NUMA binding.
+int canny_hip_selftest_cpulist_count(const char *text)
+{
+    if (!text) return 0;
+    cpu_set_t set;
+    return parse_cpulist(text, &set);
+}
+
+// CPUs local to `device` as sysfs lists them ("0-31,128-159"); what canny_hip_canny_multi_gpu binds a shard's
+// threads to.  CANNY_HIP_ERR_UNSUPPORTED when the platform does not say.
+int canny_hip_device_local_cpus(int device, char *buf, int cap)
+{
+    if (!buf || cap < 2) return CANNY_HIP_ERR_INVALID;
+    int n = 0;
+    int rc = canny_hip_device_count(&n);
+    if (rc) return rc;
+    if (device < 0 || device >= n) return CANNY_HIP_ERR_INVALID;
+    cpu_set_t set;
+    if (!device_local_cpus(device, &set)) return CANNY_HIP_ERR_UNSUPPORTED;
+    std::string out;
+    for (int c = 0; c < CPU_SETSIZE;) {
+        if (!CPU_ISSET(c, &set)) {
+            c++;
+            continue;
+        }
+        int e = c;
+        while (e + 1 < CPU_SETSIZE && CPU_ISSET(e + 1, &set)) e++;
+        if (!out.empty()) out += ",";
+        out += std::to_string(c);
+        if (e > c) out += "-" + std::to_string(e);
+        c = e + 1;
+    }
+    if ((int)out.size() + 1 > cap) return CANNY_HIP_ERR_INVALID;
+    std::memcpy(buf, out.c_str(), out.size() + 1);
     return CANNY_HIP_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -129,31 +130,40 @@ void createGaussianKernel(float *&kernel, float sigma, int *window)
     *window = w;
 }
 
+// Outputs are owned by unique_ptr until the C-ABI call has succeeded: check() throws on any failure (the reference
+// has no error channel), and a throw must not leak the planes or leave the caller with dangling out-parameters.
+using plane_ptr = std::unique_ptr<short int[]>;
+static plane_ptr new_plane(int height, int width) { return plane_ptr(new short int[count(height, width)]); }
+
 void gaussian(unsigned char *&img, float sigma, int height, int width, short int *&result)
 {
-    result = new short int[count(height, width)];
-    check(canny_hip_gaussian(ctx(), img, sigma, height, width, result), "gaussian");
+    plane_ptr out = new_plane(height, width);
+    check(canny_hip_gaussian(ctx(), img, sigma, height, width, out.get()), "gaussian");
+    result = out.release();
 }
 
 void calculateXYGradient(short int *&img, int height, int width, short int *&grad_x, short int *&grad_y)
 {
-    grad_x = new short int[count(height, width)];
-    grad_y = new short int[count(height, width)];
-    check(canny_hip_xy_gradient(ctx(), img, height, width, grad_x, grad_y), "calculateXYGradient");
+    plane_ptr gx = new_plane(height, width), gy = new_plane(height, width);
+    check(canny_hip_xy_gradient(ctx(), img, height, width, gx.get(), gy.get()), "calculateXYGradient");
+    grad_x = gx.release();
+    grad_y = gy.release();
 }
 
 void sobelOperator(short int *&img, int height, int width, short int *&magnitude, short int *&angle)
 {
-    magnitude = new short int[count(height, width)];
-    angle = new short int[count(height, width)];
-    check(canny_hip_sobel(ctx(), img, height, width, magnitude, angle), "sobelOperator");
-    delete[] img; // the reference consumes its input (src/utils.cpp:235)
+    plane_ptr mag = new_plane(height, width), ang = new_plane(height, width);
+    check(canny_hip_sobel(ctx(), img, height, width, mag.get(), ang.get()), "sobelOperator");
+    magnitude = mag.release();
+    angle = ang.release();
+    delete[] img; // the reference consumes its input (src/utils.cpp:235); on failure the caller still owns it
 }
 
 void nonmaximalSuppression(short int *&grad, short int *&angle, int height, int width, short int *&result)
 {
-    result = new short int[count(height, width)];
-    check(canny_hip_nms(ctx(), grad, angle, height, width, result), "nonmaximalSuppression");
+    plane_ptr out = new_plane(height, width);
+    check(canny_hip_nms(ctx(), grad, angle, height, width, out.get()), "nonmaximalSuppression");
+    result = out.release();
     delete[] grad;  // src/utils.cpp:306
     delete[] angle; // src/utils.cpp:307
 }
@@ -178,35 +188,33 @@ void canny(unsigned char *img, float sigma, int minVal, int maxVal, int height, 
 
 short int *cannyEdges(unsigned char *img, float sigma, int minVal, int maxVal, int height, int width)
 {
-    short int *edges = new short int[count(height, width)];
-    try {
-        check(canny_hip_canny(ctx(), img, sigma, minVal, maxVal, height, width, edges), "cannyEdges");
-    } catch (...) {
-        delete[] edges;
-        throw;
-    }
-    return edges;
+    plane_ptr edges = new_plane(height, width);
+    check(canny_hip_canny(ctx(), img, sigma, minVal, maxVal, height, width, edges.get()), "cannyEdges");
+    return edges.release();
 }
 
 // ---- cuda.h (the reference's GPU-path names; inputs are NOT freed, src/cuda.cu:446-449) -----------
 void cuda_gaussian(unsigned char *&img_h, float sigma, int height, int width, short int *&result_h)
 {
-    result_h = new short int[count(height, width)];
-    check(canny_hip_gaussian(ctx(), img_h, sigma, height, width, result_h), "cuda_gaussian");
+    plane_ptr out = new_plane(height, width);
+    check(canny_hip_gaussian(ctx(), img_h, sigma, height, width, out.get()), "cuda_gaussian");
+    result_h = out.release();
 }
 
 void cuda_sobel(short int *&img_h, int height, int width, short int *&magnitude_h, short int *&angle_h)
 {
-    magnitude_h = new short int[count(height, width)];
-    angle_h = new short int[count(height, width)];
-    check(canny_hip_sobel(ctx(), img_h, height, width, magnitude_h, angle_h), "cuda_sobel");
+    plane_ptr mag = new_plane(height, width), ang = new_plane(height, width);
+    check(canny_hip_sobel(ctx(), img_h, height, width, mag.get(), ang.get()), "cuda_sobel");
+    magnitude_h = mag.release();
+    angle_h = ang.release();
 }
 
 void cuda_nonmaixmal_suppression(short int *&magnitude_h, short int *&angle_h, int height, int width,
                                  short int *&result_h)
 {
-    result_h = new short int[count(height, width)];
-    check(canny_hip_nms(ctx(), magnitude_h, angle_h, height, width, result_h), "cuda_nonmaixmal_suppression");
+    plane_ptr out = new_plane(height, width);
+    check(canny_hip_nms(ctx(), magnitude_h, angle_h, height, width, out.get()), "cuda_nonmaixmal_suppression");
+    result_h = out.release();
 }
 
 void cuda_canny(unsigned char *img, float sigma, int min_val, int max_val, int height, int width, bool steps)

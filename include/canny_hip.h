@@ -33,8 +33,12 @@
  *     atan2/float expression for every |gx|,|gy| <= 1020, i.e. for every smoothed plane in [0,255]
  *     (everything gaussian() can produce); outside that range a gradient lying within float rounding
  *     of a bin boundary may be binned differently from the reference.
- *   - hysteresis: if min_val <= 0 the reference's result depends on its scan order whenever a
- *     candidate is below min_val; that case returns CANNY_HIP_ERR_DOMAIN.
+ *   - hysteresis / canny: if min_val <= 0 the reference's result depends on its scan order whenever a
+ *     candidate is below min_val; that case returns CANNY_HIP_ERR_DOMAIN.  So does min_val > 255 >= max_val:
+ *     the reference overwrites reached pixels with EDGE = 255 while its scan is still running, and a pixel the
+ *     scan has not reached yet then fails `< minVal` and is zeroed again (src/utils.cpp:327-334) -- e.g.
+ *     [[300,300,0,0]], min 300, max 100 gives [[255,0,0,0]].  find_edge_pixels rejects min_val > 255 likewise.
+ *     (The reference's CLI only admits thresholds in [0,255], src/main.cpp:63-76.)
  *
  * Threading: a context is bound to one device and one stream and must be used by one host thread
  * at a time; different contexts may be used concurrently (one per GPU / per host thread).
@@ -97,9 +101,10 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "overlap_hysteresis": 0 (default) / 1 -- canny() on 16 or more frames: the propagation sweeps of the first half
  *                    of the batch run on a second stream beside the Sobel+NMS kernel of the second half
  *                    (measured 1.5 % slower on 128 x 4K, kept for A/B)
- *   "tune_batch_workers", "tune_batch_chunk_mb": canny_hip_canny_batch's host threads (streams) and megabytes of
- *                    input per chunk; 0 (default) = automatic (2 x 24 MB between pinned buffers, 4 x 16 MB when a
- *                    pageable buffer has to be staged)
+ *   "tune_batch_workers", "tune_batch_chunk_mb", "tune_batch_chunk_frames": canny_hip_canny_batch's pipelines (a host
+ *                    thread with an upload, a compute and a download stream each) and the chunk size in megabytes of
+ *                    input or in frames (frames win); 0 (default) = automatic: one pipeline x 24 MB chunks between
+ *                    pinned buffers, four x 16 MB when a pageable buffer has to be staged
  *   "stream_overlap": 0 (default) / 1 -- canny_hip_dev_canny_stream: the sweeps left in flight run on a second,
  *                    high-priority stream beside the next call's Gaussian instead of in order before it
  *                    (no gain on 128 x 4K batches, kept for A/B)
@@ -150,8 +155,11 @@ int canny_hip_find_edge_pixels(canny_hip_ctx *ctx, short *edge_candidates, unsig
 /* Whole pipeline; unlike the reference's canny() the {0,255} edge map is returned in `edges`. */
 int canny_hip_canny(canny_hip_ctx *ctx, const unsigned char *img, float sigma, int min_val, int max_val,
                     int height, int width, short *edges);
-/* n_frames contiguous frames in, n_frames edge maps out; H2D, kernels and D2H of successive chunks
- * overlap on separate streams with pinned staging (BASELINE config 3). */
+/* n_frames contiguous frames in, n_frames edge maps out, frame i of the output = canny() of frame i (the
+ * reference calls canny() once per captured frame, src/main.cpp:120-137).  The batch is cut into chunks; the
+ * upload of chunk j+1, the kernels of chunk j and the download of chunk j-1 run concurrently on three streams
+ * chained by events (BASELINE config 3).  Buffers from canny_hip_host_alloc (or any pinned / registered host
+ * memory) are DMA'd in place; pageable buffers are staged through pinned memory by the pipeline threads. */
 int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
                           int max_val, int height, int width, short *edges);
 /* Same, but the edge maps come back as 8-bit planes (NOEDGE = 0, EDGE = 255: the values of src/utils.h:5-6
@@ -160,10 +168,26 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
  * this one. */
 int canny_hip_canny_batch_u8(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
                              int max_val, int height, int width, unsigned char *edges);
-/* Shards n_frames by contiguous ranges over n_devices GPUs (devices 0..n_devices-1), one host
- * thread and one context per GPU, no collective (BASELINE config 5).  n_devices <= 0 = all. */
+/* Shards n_frames by contiguous ranges over n_devices GPUs (devices 0..n_devices-1), one host thread and one
+ * context per GPU, each running the batch pipeline above on its shard; no collective (BASELINE config 5: the
+ * reference has no multi-GPU path, frames are independent).  n_devices <= 0 = all.  The per-device contexts
+ * (pipelines, streams, staging) are created on first use and kept until canny_hip_multi_gpu_release(); each
+ * shard's threads are bound to the CPUs local to its GPU (sysfs local_cpulist) for the duration of the call.
+ * One sharded call runs at a time per process.  Pinned caller buffers are DMA'd in place (allocate them on
+ * the right NUMA node for best results); pageable ones are staged by 4 pipeline threads per GPU. */
 int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
                               int height, int width, short *edges, int n_devices);
+int canny_hip_canny_multi_gpu_u8(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
+                                 int height, int width, unsigned char *edges, int n_devices);
+/* Process-wide options of the sharder: "tune_batch_workers" / "tune_batch_chunk_mb" / "tune_batch_chunk_frames"
+ * (applied to every shard's pipeline), "numa_affinity" 1 (default) / 0, "allow_device_reuse" 0 (default) / 1:
+ * n_devices may exceed the device count, shard s then runs on device s % count (exercises the sharder with N > 1
+ * on a one-GPU box; no use in production). */
+int canny_hip_multi_gpu_set_option(const char *name, int value);
+/* Destroys the cached per-device contexts. */
+int canny_hip_multi_gpu_release(void);
+/* CPUs local to `device` in sysfs list form ("0-31,128-159"); CANNY_HIP_ERR_UNSUPPORTED if the platform does not say. */
+int canny_hip_device_local_cpus(int device, char *buf, int cap);
 /* Frame range [begin, end) of shard `rank` of `world` (what canny_hip_canny_multi_gpu and bench.py use). */
 int canny_hip_shard_range(int n_frames, int rank, int world, int *begin, int *end);
 
@@ -227,6 +251,9 @@ int canny_hip_selftest_div_fma(canny_hip_ctx *ctx, float divisor, float c, unsig
                                float *largest_mismatching_dividend);
 /* Entry `index` of the built-in (divisor, c) table the kernels use; CANNY_HIP_ERR_INVALID past the end. */
 int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c);
+/* Host-only: number of CPUs in a sysfs-style list ("0-3,8,10-11" -> 7; 0 if malformed) -- the parser behind the
+ * sharder's NUMA binding. */
+int canny_hip_selftest_cpulist_count(const char *text);
 
 #ifdef __cplusplus
 }

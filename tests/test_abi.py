@@ -104,3 +104,24 @@ def test_cli_keeps_reference_grammar():
     assert r.returncode == 0 and "minVal must be in the range of [0,255]" in r.stderr
     r = subprocess.run([exe, "1.0", "50", "300"], capture_output=True, text=True)
     assert r.returncode == 0 and "maxVal must be in the range of [0,255]" in r.stderr
+
+
+@pytest.mark.parametrize("text,count", [("0-3,8,10-11", 7), ("0", 1), ("0-31,128-159\n", 64), ("5-5", 1), ("", 0),
+                                        ("3-1", 0), ("a-b", 0), ("1,,2", 2)])
+def test_cpulist_parser_behind_the_numa_binding(text, count):
+    """canny_hip_canny_multi_gpu binds each shard's threads to the GPU's sysfs local_cpulist; the parser is host
+    logic and testable without a GPU."""
+    assert capi.cpulist_count(text) == count
+
+
+def test_multi_gpu_options_are_validated_without_a_gpu():
+    for name in ("tune_batch_workers", "tune_batch_chunk_mb", "tune_batch_chunk_frames", "allow_device_reuse",
+                 "numa_affinity"):
+        capi.multi_gpu_set_option(name, 1)
+        capi.multi_gpu_set_option(name, 0)
+    capi.multi_gpu_set_option("numa_affinity", 1)
+    with pytest.raises(capi.CannyHipError):
+        capi.multi_gpu_set_option("no_such_option", 1)
+    with pytest.raises(capi.CannyHipError):
+        capi.multi_gpu_set_option("allow_device_reuse", 2)
+    capi.multi_gpu_release()  # nothing cached: a no-op

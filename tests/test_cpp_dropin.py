@@ -76,12 +76,18 @@ def test_cli_end_to_end(tmp_path, flags):
     want = oracle.canny(img, 1.4, 50, 150, stages=True)
     assert np.array_equal(got, want["edges"].astype(np.uint8))       # {0,255} survives min-max normalisation
     if "-s" in flags:
-        sm = _read_pgm(tmp_path / "canny_step1_gaussian.pgm")
-        ref = want["smoothed"].astype(np.float64)
-        norm = np.rint((ref - ref.min()) * (255.0 / (ref.max() - ref.min()))).astype(np.uint8)
-        assert np.array_equal(sm, norm)
-        assert os.path.exists(tmp_path / "canny_step2_gradient.pgm")
-        assert os.path.exists(tmp_path / "canny_step3_nonmaximal.pgm")
+        # the reference shows each intermediate through normalize(..., 0, 255, NORM_MINMAX) + convertTo(CV_8U)
+        # (src/utils.cpp:440-475): gaussian, gradient magnitude, suppressed magnitude.  OpenCV is not in this image,
+        # so the min-max stretch itself is the documented formula, not OpenCV's code ("parity unpinned" for the
+        # display scaling only; the planes underneath are the oracle's, bit for bit).
+        def norm(plane):
+            ref = plane.astype(np.float64)
+            return np.rint((ref - ref.min()) * (255.0 / (ref.max() - ref.min()))).astype(np.uint8)
+
+        for fname, key in (("canny_step1_gaussian.pgm", "smoothed"), ("canny_step2_gradient.pgm", "magnitude"),
+                           ("canny_step3_nonmaximal.pgm", "nms")):
+            got_step = _read_pgm(tmp_path / fname)
+            assert np.array_equal(got_step, norm(want[key])), fname
 
 
 @pytest.mark.gpu

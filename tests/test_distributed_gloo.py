@@ -1,10 +1,11 @@
-"""N>1 path on the CPU: two gloo ranks shard a batch with the product's sharding rules, each rank runs
+"""N>1 path on the CPU: gloo ranks (2 and 3 of them, even, uneven and empty shards) shard a batch with the product's sharding rules, each rank runs
 its shard (here through the oracle, since there is no GPU in the build container), and rank 0 checks
 that the gathered result equals the single-process result and that the timing reduction is a MAX."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -12,7 +13,7 @@ import torch.multiprocessing as mp
 from canny_edge_amd import sharding
 from canny_edge_amd.synth import synth_frame
 
-N_FRAMES, H, W = 5, 48, 64
+H, W = 48, 64
 
 
 def _free_port():
@@ -21,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, N_FRAMES):
     import oracle
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -45,19 +46,26 @@ def _worker(rank, world, port, out_q):
         dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_max_timing():
-    world = 2
+@pytest.mark.parametrize("n_frames,world,range0", [(5, 2, (0, 3)), (7, 3, (0, 3)), (2, 3, (0, 1))],
+                         ids=["5_frames_2_ranks", "7_frames_3_ranks", "2_frames_3_ranks_one_empty_shard"])
+def test_rank_sharding_and_max_timing(n_frames, world, range0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_frames)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, slow, rng0 = q.get(timeout=120)
+    ok, slow, rng0 = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok, "gathered shards differ from the single-process result"
-    assert slow == 2.0, "timing must be the MAX over ranks"
-    assert rng0 == (0, 3)
+    assert slow == float(world), "timing must be the MAX over ranks"
+    assert rng0 == range0
+    # every frame belongs to exactly one rank, ranges are contiguous and ordered, sizes differ by at most one
+    ranges = [sharding.shard_range(n_frames, r, world) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == n_frames
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    sizes = [e - b for b, e in ranges]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
     assert sharding.aggregate_throughput(10, 2, 4.0) == 5.0

@@ -12,7 +12,9 @@ its traffic -- is the raw counter and marked as such)."""
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
 
 FRAMES, HEIGHT, WIDTH = 128, 2160, 3840  # bench.py's default workload (what tools/pmc_passes.sh runs)
@@ -64,8 +66,12 @@ def main():
         "_comment": "HBM traffic per launch in bench.py's default workload from rocprofv3 PMC passes "
                     "(tools/pmc_passes.sh, one counter per pass, --kernel-trace only); units and the gfx950 "
                     "FETCH_SIZE x2 correction per MI355X_MICROARCH.md (HBM).  Raw per-dispatch rows: "
-                    "profiles/r01_pmc/fetch_counter_collection.csv, write_counter_collection.csv.",
+                    "profiles/rNN_pmc/fetch_counter_collection.csv, write_counter_collection.csv.",
         "frames": FRAMES, "height": HEIGHT, "width": WIDTH, "kernels": kernels,
+        # bench.py reports `traffic` only while the kernel source is the one these counters were collected on
+        "kernel_source_sha256": hashlib.sha256(open(os.path.join(
+            os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "canny_edge_amd", "csrc",
+            "canny_sobel_nms_march.hip"), "rb").read()).hexdigest(),
     }
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))

@@ -4,7 +4,7 @@
 # Each pass is its own run with --kernel-trace only (never combined with sys/hip tracing).
 set -u
 OUT=${1:-gpurun_out/pmc}
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-check --spinup-seconds 0"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-check --spinup-seconds 0 --h2h-frames 0"
 ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

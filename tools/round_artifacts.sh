@@ -10,7 +10,7 @@ mkdir -p gpurun_out
 timeout -k 10 420 python3 bench.py --steps 20 --warmup 3 > gpurun_out/bench.json.log 2> gpurun_out/bench.err || { echo "bench failed"; tail -5 gpurun_out/bench.err; exit 1; }
 tail -c 600 gpurun_out/bench.json.log; echo
 rm -rf gpurun_out/prof
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$ROOT/gpurun_out/prof.log" 2>&1) || { echo "rocprofv3 stats failed"; tail -5 gpurun_out/prof.log; exit 1; }
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --h2h-frames 0 > "$ROOT/gpurun_out/prof.log" 2>&1) || { echo "rocprofv3 stats failed"; tail -5 gpurun_out/prof.log; exit 1; }
 echo "stats done"
 rm -rf gpurun_out/pmc
 timeout -k 10 600 bash tools/pmc_passes.sh gpurun_out/pmc > gpurun_out/pmc_passes.log 2>&1 || { echo "pmc failed"; tail -5 gpurun_out/pmc_passes.log; exit 1; }

@@ -113,12 +113,16 @@ struct canny_hip_ctx {
     int sobel_nms_path = 0;  // 0 auto, 1 LDS tile, 2 march
     int tune_sobel_seg = 0;  // A/B knob of the marching Sobel+NMS kernel: rows per segment, 0 = automatic
     int fuse_classify = 1;   // canny(): Sobel+NMS emits the hysteresis bit-planes directly when it can
+    // canny(): the smoothed plane between the Gaussian and the fused Sobel+NMS kernel as bytes (its values lie in
+    // [0,255], src/utils.cpp:62): 0 = s16 plane, 1 = u8 plane, 2 = u8 plane converted with v_cvt_pk_u8_f32
+    int smoothed_u8 = 0;
     // canny_hip_canny_batch: number of pipelines (host threads, each with an H2D, a compute and a D2H stream and a
     // ring of chunk slots) that each take every n-th chunk, and the chunk size (megabytes of input, or frames).
     // 0 = automatic, see canny_batch_impl.
     int batch_workers = 0;
     int batch_chunk_mb = 0;
     int batch_chunk_frames = 0;
+    int batch_pipe_mode = 0; // A/B: 0 = three streams per pipeline, 1 = everything in order on one stream per pipeline
     // the pipelines live as long as the context: creating a sub-context with its streams and allocating its
     // staging costs ~10 ms per call, a sixth of a 1024 x 1080p batch
     struct BatchPipe;
@@ -272,12 +276,30 @@ bool hysteresis_order_dependent(int min_val, int max_val) { return min_val > 255
 size_t npx(int height, int width, int n_frames) { return (size_t)height * (size_t)width * (size_t)n_frames; }
 
 // ---- device-level stages ------------------------------------------------------------------------
-int dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int h, int w, int n, short *d_out)
+// Can the Gaussian hand its result to Sobel+NMS as bytes?  (marching symmetric-tap kernel on both sides)
+bool gaussian_u8_possible(const canny_hip_ctx *ctx, const GaussTaps &taps, int h, int w)
 {
+    float min_tap = 1.0f;
+    for (int k = 0; k <= 2 * taps.center; k++)
+        if (taps.tap[k] > 0.0f && taps.tap[k] < min_tap) min_tap = taps.tap[k];
+    return ctx->gaussian_path != 1 && gaussian_march_supported(taps.center, h, w) && min_tap >= 0x1p-48f &&
+           gaussian_march_u8_supported(taps) && sobel_nms_u8_input_supported();
+}
+
+// u8_mode: 0 = s16 plane in d_out; 1 / 2 = u8 plane in d_out (2: v_cvt_pk_u8_f32), only if gaussian_u8_possible()
+int dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int h, int w, int n, void *d_out_any,
+                 int u8_mode = 0)
+{
+    short *d_out = (short *)d_out_any;
     GaussTaps taps;
     int rc = make_taps(sigma, taps);
     if (rc) return rc;
     StageTimer tm(ctx, CANNY_HIP_STAGE_GAUSSIAN);
+    if (u8_mode) {
+        if (!gaussian_u8_possible(ctx, taps, h, w)) return CANNY_HIP_ERR_UNSUPPORTED;
+        HIP_TRY(ctx, launch_gaussian_march_u8(d_img, (uint8_t *)d_out_any, h, w, n, taps, ctx->stream, u8_mode == 2));
+        return CANNY_HIP_OK;
+    }
     // The marching kernel divides through a precomputed reciprocal, which equals the IEEE quotient for every
     // dividend >= 2^-102 (canny_hip_selftest_div).  Non-zero dividends are >= min_tap (row sums, pixels >= 1)
     // and >= ~min_tap^2 (column sums), so min_tap >= 2^-48 keeps them all above 2^-97; narrower taps
@@ -468,8 +490,23 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
     if (rc) return rc;
     HIP_TRY(ctx, ctx->smoothed.ensure(npx(h, w, n) * sizeof(short)));
     short *sm = (short *)ctx->smoothed.p;
-    if ((rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm))) return rc;
-    if (ctx->fuse_classify && ctx->sobel_nms_path != 1 && sobel_nms_classify_supported(h, w, lo)) {
+    const bool fused = ctx->fuse_classify && ctx->sobel_nms_path != 1 && sobel_nms_classify_supported(h, w, lo);
+    int sm_u8 = 0; // the smoothed plane as bytes: only between the two marching kernels of the fused path
+    if (fused && ctx->smoothed_u8) {
+        GaussTaps taps;
+        if ((rc = make_taps(sigma, taps))) return rc;
+        if (gaussian_u8_possible(ctx, taps, h, w)) sm_u8 = ctx->smoothed_u8;
+    }
+    if ((rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm, sm_u8))) return rc;
+    // Sobel+NMS+classify on the s16 or the u8 smoothed plane
+    auto fused_sobel = [&](const short *smp, short *edges, uint64_t *S, uint64_t *C, const HystGeom &gg, int ev,
+                           const LaunchEvents &le) -> hipError_t {
+        return sm_u8 ? launch_sobel_nms_classify_march_u8in((const uint8_t *)smp, edges, S, C, gg, lo, hi, ev,
+                                                            ctx->stream, ctx->tune_sobel_seg, le)
+                     : launch_sobel_nms_classify_march(smp, edges, S, C, gg, lo, hi, ev, ctx->stream,
+                                                       ctx->tune_sobel_seg, le);
+    };
+    if (fused) {
         // Sobel+NMS writes the hysteresis bit-planes directly: the suppressed magnitudes never reach memory
         // and the classify pass disappears (canny() does not return them; the stage API still does).
         HystGeom g = make_hyst_geom(h, w, n);
@@ -498,8 +535,7 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
             B.host_dev += 4;
             {
                 StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
-                HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, A.S, (uint64_t *)A.C, gA, lo, hi, edge_value,
-                                                             ctx->stream, ctx->tune_sobel_seg, tm.launch_events()));
+                HIP_TRY(ctx, fused_sobel(sm, d_edges, A.S, (uint64_t *)A.C, gA, edge_value, tm.launch_events()));
             }
             HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
@@ -507,9 +543,8 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
             if ((rc = lane_launch_chunk(ctx, A))) return rc;
             {
                 StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
-                HIP_TRY(ctx, launch_sobel_nms_classify_march(sm + px_a, d_edges + px_a, B.S, (uint64_t *)B.C, gB, lo, hi,
-                                                             edge_value, ctx->stream, ctx->tune_sobel_seg,
-                                                             tm.launch_events()));
+                const short *smB = sm_u8 ? (const short *)((const uint8_t *)sm + px_a) : sm + px_a;
+                HIP_TRY(ctx, fused_sobel(smB, d_edges + px_a, B.S, (uint64_t *)B.C, gB, edge_value, tm.launch_events()));
             }
             if ((rc = lane_launch_chunk(ctx, B))) return rc;
             for (PropLane *L : {&A, &B}) {
@@ -525,8 +560,7 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
         if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc; // the kernel below writes in-image bytes only
         {
             StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
-            HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, S, C, g, lo, hi, edge_value, ctx->stream,
-                                                         ctx->tune_sobel_seg, tm.launch_events()));
+            HIP_TRY(ctx, fused_sobel(sm, d_edges, S, C, g, edge_value, tm.launch_events()));
         }
         // d_edges now holds the strong pixels; the sweeps add every pixel they promote: no finalize pass
         return run_propagation(ctx, g, /*speculative=*/false, []() -> int { return CANNY_HIP_OK; }, d_edges, edge_value);
@@ -573,7 +607,14 @@ int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma
     }
     HIP_TRY(ctx, ctx->smoothed.ensure(npx(h, w, n) * sizeof(short)));
     short *sm = (short *)ctx->smoothed.p;
-    int rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm);
+    int sm_u8 = 0;
+    if (ctx->smoothed_u8) {
+        GaussTaps taps;
+        int rt = make_taps(sigma, taps);
+        if (rt) return rt;
+        if (gaussian_u8_possible(ctx, taps, h, w)) sm_u8 = ctx->smoothed_u8;
+    }
+    int rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm, sm_u8);
     if (rc) return rc;
     if ((rc = finish_pending(ctx))) return rc; // host waits here while the Gaussian runs
     HystGeom g = make_hyst_geom(h, w, n);
@@ -582,9 +623,14 @@ int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma
     if ((rc = prepare_hyst(ctx, g, /*zero_pad=*/true))) return rc;
     {
         StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
-        HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, (uint64_t *)ctx->plane_s.p, (uint64_t *)ctx->plane_c.p,
-                                                     g, lo, hi, edge_value, ctx->stream, ctx->tune_sobel_seg,
-                                                     tm.launch_events()));
+        if (sm_u8)
+            HIP_TRY(ctx, launch_sobel_nms_classify_march_u8in((const uint8_t *)sm, d_edges, (uint64_t *)ctx->plane_s.p,
+                                                              (uint64_t *)ctx->plane_c.p, g, lo, hi, edge_value,
+                                                              ctx->stream, ctx->tune_sobel_seg, tm.launch_events()));
+        else
+            HIP_TRY(ctx, launch_sobel_nms_classify_march(sm, d_edges, (uint64_t *)ctx->plane_s.p,
+                                                         (uint64_t *)ctx->plane_c.p, g, lo, hi, edge_value, ctx->stream,
+                                                         ctx->tune_sobel_seg, tm.launch_events()));
     }
     ctx->pend = main_lane(ctx, g, d_edges, edge_value);
     if (ctx->stream_overlap) {
@@ -769,10 +815,12 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "sobel_nms_path") && value <= 2) ctx->sobel_nms_path = value;
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
     else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
+    else if (!std::strcmp(name, "smoothed_u8") && value <= 2) ctx->smoothed_u8 = value;
     else if (!std::strcmp(name, "overlap_hysteresis") && value <= 1) ctx->overlap_hysteresis = value;
     else if (!std::strcmp(name, "tune_batch_workers") && value <= 16) ctx->batch_workers = value;
     else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) ctx->batch_chunk_mb = value;
     else if (!std::strcmp(name, "tune_batch_chunk_frames") && value <= 65535) ctx->batch_chunk_frames = value;
+    else if (!std::strcmp(name, "tune_batch_pipe_mode") && value <= 1) ctx->batch_pipe_mode = value;
     else if (!std::strcmp(name, "stream_overlap") && value <= 1) {
         int rc = bind(ctx);
         if (rc || (rc = finish_pending(ctx))) return rc;
@@ -1066,6 +1114,9 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         Pipe &P = *ctx->batch_pool[wid];
         canny_hip_ctx *sub = P.sub;
         int &st = status[wid];
+        // A/B mode 1: uploads and downloads in order on the compute stream (overlap only between pipelines)
+        const hipStream_t s_h2d = ctx->batch_pipe_mode ? sub->stream : P.s_h2d;
+        const hipStream_t s_d2h = ctx->batch_pipe_mode ? sub->stream : P.s_d2h;
         if (hipSetDevice(device) != hipSuccess) { // a new thread starts on device 0
             st = CANNY_HIP_ERR_RUNTIME;
             return;
@@ -1105,8 +1156,8 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
                 std::memcpy(S.pin_in.p, src, frame_px * nf);
                 src = (const unsigned char *)S.pin_in.p;
             }
-            hipError_t err = hipMemcpyAsync(S.d_in.p, src, frame_px * nf, hipMemcpyHostToDevice, P.s_h2d);
-            if (err == hipSuccess) err = hipEventRecord(S.ev_h2d, P.s_h2d);
+            hipError_t err = hipMemcpyAsync(S.d_in.p, src, frame_px * nf, hipMemcpyHostToDevice, s_h2d);
+            if (err == hipSuccess) err = hipEventRecord(S.ev_h2d, s_h2d);
             return err;
         };
         // the staged output of chunk j reaches the caller's pageable buffer
@@ -1144,11 +1195,11 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             where = "batch D2H";
             unsigned char *dst = (unsigned char *)edges + (size_t)f0 * frame_px * out_elem;
             const size_t bytes = frame_px * nf * out_elem;
-            if ((e = hipStreamWaitEvent(P.s_d2h, S.ev_comp, 0)) != hipSuccess) break;
+            if ((e = hipStreamWaitEvent(s_d2h, S.ev_comp, 0)) != hipSuccess) break;
             if ((e = hipMemcpyAsync(out_pinned ? (void *)dst : S.pin_out.p, d_res, bytes, hipMemcpyDeviceToHost,
-                                    P.s_d2h)) != hipSuccess)
+                                    s_d2h)) != hipSuccess)
                 break;
-            if ((e = hipEventRecord(S.ev_d2h, P.s_d2h)) != hipSuccess) break;
+            if ((e = hipEventRecord(S.ev_d2h, s_d2h)) != hipSuccess) break;
             S.d2h_issued = true;
             if (!out_pinned) {
                 S.retire_dst = dst;
@@ -1158,9 +1209,9 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         }
         if (e == hipSuccess && st == CANNY_HIP_OK && my_chunks > 0) e = retire(my_chunks - 1);
         // nothing of this call may still be in flight when it returns (also after an error: the slots are reused)
-        hipError_t e2 = hipStreamSynchronize(P.s_h2d);
+        hipError_t e2 = hipStreamSynchronize(s_h2d);
         hipError_t e3 = hipStreamSynchronize(sub->stream);
-        hipError_t e4 = hipStreamSynchronize(P.s_d2h);
+        hipError_t e4 = hipStreamSynchronize(s_d2h);
         if (e == hipSuccess) e = e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4);
         if (e != hipSuccess && st == CANNY_HIP_OK) st = fail(sub, e, where);
         if (st != CANNY_HIP_OK) errors[wid] = sub->last_error;
@@ -1435,6 +1486,30 @@ int canny_hip_dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int hei
     return dev_sobel_nms(ctx, d_smoothed, height, width, n_frames, d_nms);
 }
 
+int canny_hip_dev_gaussian_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int height, int width,
+                              int n_frames, unsigned char *d_result, int pk_convert)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_img || !d_result) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    return dev_gaussian(ctx, d_img, sigma, height, width, n_frames, d_result, pk_convert ? 2 : 1);
+}
+
+int canny_hip_dev_sobel_nms_u8in(canny_hip_ctx *ctx, const unsigned char *d_smoothed, int height, int width,
+                                 int n_frames, short *d_nms)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_smoothed || !d_nms) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    if (height < 2 || width < 2 || !sobel_nms_u8_input_supported()) return CANNY_HIP_ERR_UNSUPPORTED;
+    StageTimer tm(ctx, CANNY_HIP_STAGE_SOBEL_NMS, nullptr, /*attached=*/true);
+    HIP_TRY(ctx, launch_sobel_nms_march_u8in(d_smoothed, d_nms, height, width, n_frames, ctx->stream,
+                                             ctx->tune_sobel_seg, tm.launch_events()));
+    return CANNY_HIP_OK;
+}
+
 int canny_hip_dev_hysteresis(canny_hip_ctx *ctx, short *d_edge_candidates, int height, int width, int n_frames,
                              int min_val, int max_val)
 {
@@ -1573,6 +1648,22 @@ int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long
                            float *largest_mismatching_dividend)
 {
     return selftest_div_common(ctx, divisor, 0, 0.0f, mismatches, largest_mismatching_dividend);
+}
+
+int canny_hip_selftest_cvt_pk_u8(canny_hip_ctx *ctx, unsigned long long *mismatches, float *largest_mismatching_input)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!mismatches || !largest_mismatching_input) return CANNY_HIP_ERR_INVALID;
+    HIP_TRY(ctx, ctx->io[0].ensure(2 * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->io[0].p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_selftest_cvt_pk_u8(0u, 0x43800000u /* 256.0f */, (unsigned long long *)ctx->io[0].p, ctx->stream));
+    unsigned long long res[2] = {0, 0};
+    if ((rc = d2h_sync(ctx, res, ctx->io[0].p, sizeof(res)))) return rc;
+    *mismatches = res[0];
+    unsigned bits = (unsigned)res[1];
+    std::memcpy(largest_mismatching_input, &bits, sizeof(float));
+    return CANNY_HIP_OK;
 }
 
 int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c)

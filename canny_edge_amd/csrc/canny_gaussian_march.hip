@@ -75,7 +75,8 @@ __device__ __forceinline__ float div_by(float a, float b, float y)
 
 struct GaussJob {
     const uint8_t *fimg;
-    int16_t *fout;
+    int16_t *fout;     // s16 plane ...
+    uint8_t *fout8;    // ... or, in the OUT_U8 kernels, the u8 plane (same values: the quotients lie in [0,255])
     int H, W, ybeg, yend, x0, lane;
 };
 
@@ -289,7 +290,10 @@ __device__ __forceinline__ void for_each_phase(F &&f, std::integer_sequence<int,
 // of multiplying: ds_read_b32 issues on the LDS port beside the VALU work of other waves, and this kernel is
 // bound by VALU issue.  The lookups of one instruction hit 64 pixels 4 columns apart -- nearly equal values,
 // i.e. neighbouring or identical words: few bank conflicts on natural images.
-template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV, bool USE_LUT>
+// OUT_U8: the smoothed plane is stored as bytes (src/utils.cpp:62: (short)(sum/count) always lies in [0,255]), one
+// dword store per lane and row instead of an 8-byte one; PK_U8 additionally converts and packs with
+// v_cvt_pk_u8_f32 (one instruction per pixel instead of v_cvt_i32_f32 + a share of the shifts/ors).
+template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV, bool USE_LUT, bool OUT_U8 = false, bool PK_U8 = false>
 __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussTaps &t, const float *lut,
                                                 float fma_c = 0.0f)
 {
@@ -335,7 +339,7 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
     // 32-bit lane offset" (saddr form).  Because the variable itself is what the asm "changes", its old value is
     // dead at that point and no register copy is needed (opaque_offset() on a loop-invariant value costs a v_mov
     // per use).  Both are only used where x0 >= 0.
-    uint32_t ld_off = (uint32_t)x0, st_off = 2u * (uint32_t)x0;
+    uint32_t ld_off = (uint32_t)x0, st_off = (OUT_U8 ? 1u : 2u) * (uint32_t)x0;
 
     auto load_row = [&](int r) -> uint32_t {
         if (ROW_EDGE && (r < 0 || r >= H)) return 0u; // wave-uniform
@@ -463,23 +467,52 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         }
         // float -> short truncates toward zero (src/utils.cpp:62)
         auto quot = [&](float a) { return FMA_DIV ? __fmaf_rn(a, fma_c, a) : div_by(a, cnt_v, inv_v); };
-        const int o0 = (int)quot(acc[DONE][0]), o1 = (int)quot(acc[DONE][1]);
-        const int o2 = (int)quot(acc[DONE][2]), o3 = (int)quot(acc[DONE][3]);
         uint2 pk;
-        // quotients of non-negative sums: 0 <= o < 65536, so the low halves need no mask (one v_lshl_or_b32 per pair)
-        pk.x = (uint32_t)o0 | ((uint32_t)o1 << 16);
-        pk.y = (uint32_t)o2 | ((uint32_t)o3 << 16);
+        if (OUT_U8 && PK_U8) {
+            // v_cvt_pk_u8_f32 truncates toward zero like the cast (checked for every float in [0,256] by
+            // canny_hip_selftest_cvt_pk_u8) and drops the result into byte k of the accumulating dword
+            uint32_t w = 0u;
+            asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(w) : "v"(quot(acc[DONE][0])));
+            asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(w) : "v"(quot(acc[DONE][1])));
+            asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(w) : "v"(quot(acc[DONE][2])));
+            asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(quot(acc[DONE][3])));
+            pk.x = w;
+            pk.y = 0u;
+        } else {
+            const int o0 = (int)quot(acc[DONE][0]), o1 = (int)quot(acc[DONE][1]);
+            const int o2 = (int)quot(acc[DONE][2]), o3 = (int)quot(acc[DONE][3]);
+            if (OUT_U8) {
+                // quotients of non-negative sums <= 255 * (1 + ulps): 0 <= o <= 255
+                pk.x = ((uint32_t)o0 | ((uint32_t)o1 << 8)) | (((uint32_t)o2 | ((uint32_t)o3 << 8)) << 16);
+                pk.y = 0u;
+            } else {
+                // quotients of non-negative sums: 0 <= o < 65536, so the low halves need no mask (one v_lshl_or_b32 per pair)
+                pk.x = (uint32_t)o0 | ((uint32_t)o1 << 16);
+                pk.y = (uint32_t)o2 | ((uint32_t)o3 << 16);
+            }
+        }
         asm volatile("" : "+v"(pk.x), "+v"(pk.y)); // materialise here, whatever the branch below does
         if (in_seg && owner) {
             // owner lanes have x0 >= 0; byte offset so that no 64-bit shift is needed per lane
             asm volatile("" : "+v"(st_off));
-            int16_t *dst = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(jb.fout + (size_t)y * W) + st_off);
-            if (!COL_EDGE || full4) {
-                __builtin_memcpy(dst, &pk, 8);
+            if (OUT_U8) {
+                uint8_t *dst = jb.fout8 + (size_t)y * W + st_off;
+                if (!COL_EDGE || full4) {
+                    __builtin_memcpy(dst, &pk.x, 4);
+                } else {
+                    dst[0] = (uint8_t)pk.x;
+                    if (x0 + 1 < W) dst[1] = (uint8_t)(pk.x >> 8);
+                    if (x0 + 2 < W) dst[2] = (uint8_t)(pk.x >> 16);
+                }
             } else {
-                dst[0] = (int16_t)pk.x;
-                if (x0 + 1 < W) dst[1] = (int16_t)(pk.x >> 16);
-                if (x0 + 2 < W) dst[2] = (int16_t)pk.y;
+                int16_t *dst = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(jb.fout + (size_t)y * W) + st_off);
+                if (!COL_EDGE || full4) {
+                    __builtin_memcpy(dst, &pk, 8);
+                } else {
+                    dst[0] = (int16_t)pk.x;
+                    if (x0 + 1 < W) dst[1] = (int16_t)(pk.x >> 16);
+                    if (x0 + 2 < W) dst[2] = (int16_t)pk.y;
+                }
             }
         }
     };
@@ -509,9 +542,9 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 
 // Live state per lane: 4(2C+1) open sums + 4(C+1) products + ~30; without an occupancy target the scheduler
 // interleaves several rows' products and doubles that.
-template <int C, bool USE_LUT>
+template <int C, bool USE_LUT, bool OUT_U8 = false, bool PK_U8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 5 ? 5 : 4)))
-void gauss_sym_kernel(const uint8_t *__restrict__ img, int16_t *__restrict__ out, int H, int W, int n_strips,
+void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, int H, int W, int n_strips,
                       int n_segs, int seg_rows, int total_waves, GaussTaps t, int use_fma_div, float fma_c)
 {
     using K = MarchCfg<C>;
@@ -538,7 +571,8 @@ void gauss_sym_kernel(const uint8_t *__restrict__ img, int16_t *__restrict__ out
     jb.yend = min(H, jb.ybeg + seg_rows);
     jb.x0 = s * K::SW + (lane - K::HL) * 4; // first of this lane's 4 columns (halo lanes may be outside)
     jb.fimg = img + (size_t)f * H * W;
-    jb.fout = out + (size_t)f * H * W;
+    jb.fout = (int16_t *)out + (size_t)f * H * W;
+    jb.fout8 = (uint8_t *)out + (size_t)f * H * W;
 
     // the strip's lanes span columns [s*SW - 4HL, s*SW + SW + 4HL)
     const bool col_edge = (s * K::SW - 4 * K::HL < 0) || (s * K::SW + K::SW + 4 * K::HL > W);
@@ -546,16 +580,16 @@ void gauss_sym_kernel(const uint8_t *__restrict__ img, int16_t *__restrict__ out
     const bool row_edge = (jb.ybeg - C < 0) || (jb.yend + C + K::RING >= H);
     if (col_edge) {
         if (row_edge)
-            gauss_sym_strip<C, true, true, false, USE_LUT>(jb, t, lut);
+            gauss_sym_strip<C, true, true, false, USE_LUT, OUT_U8, PK_U8>(jb, t, lut);
         else
-            gauss_sym_strip<C, true, false, false, USE_LUT>(jb, t, lut);
+            gauss_sym_strip<C, true, false, false, USE_LUT, OUT_U8, PK_U8>(jb, t, lut);
     } else {
         if (row_edge)
-            gauss_sym_strip<C, false, true, false, USE_LUT>(jb, t, lut);
+            gauss_sym_strip<C, false, true, false, USE_LUT, OUT_U8, PK_U8>(jb, t, lut);
         else if (use_fma_div)
-            gauss_sym_strip<C, false, false, true, USE_LUT>(jb, t, lut, fma_c);
+            gauss_sym_strip<C, false, false, true, USE_LUT, OUT_U8, PK_U8>(jb, t, lut, fma_c);
         else
-            gauss_sym_strip<C, false, false, false, USE_LUT>(jb, t, lut);
+            gauss_sym_strip<C, false, false, false, USE_LUT, OUT_U8, PK_U8>(jb, t, lut);
     }
 }
 
@@ -586,6 +620,7 @@ __global__ __launch_bounds__(MarchCfg<C>::WPB * 64) void gauss_march_kernel(
     jb.x0 = s * K::SW + (lane - K::HL) * 4; // first of this lane's 4 columns (halo lanes may be outside)
     jb.fimg = img + (size_t)f * H * W;
     jb.fout = out + (size_t)f * H * W;
+    jb.fout8 = nullptr;
 
     if (lane < 4 * K::HL) { // the pads of the row buffer are only ever read by halo lanes; keep them finite
         rowbuf[lane] = 0.0f;
@@ -673,9 +708,11 @@ hipError_t launch_selftest_div(float b, int use_fma, float c, unsigned first_bit
     return hipGetLastError();
 }
 
+// out_u8: 0 = s16 plane, 1 = u8 plane (v_cvt_i32_f32 + shifts/ors), 2 = u8 plane (v_cvt_pk_u8_f32); the u8 forms
+// exist for the symmetric-tap kernel with the product table only
 template <int C>
-static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, int width, int n_frames,
-                                 const GaussTaps &taps, hipStream_t stream)
+static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int width, int n_frames,
+                                 const GaussTaps &taps, hipStream_t stream, int out_u8)
 {
     using K = MarchCfg<C>;
     int n_strips = (width + K::SW - 1) / K::SW;
@@ -716,34 +753,102 @@ static hipError_t launch_march_c(const uint8_t *img, int16_t *out, int height, i
             use_fma = 1;
             std::memcpy(&fma_c, &e[1], sizeof(fma_c));
         }
-    if (symmetric && march_variant == 0)
+    if (out_u8 && !(symmetric && march_variant == 0)) return hipErrorNotSupported;
+    if (out_u8 == 2)
+        hipLaunchKernelGGL((gauss_sym_kernel<C, true, true, true>), dim3(blocks), dim3(256), 0, stream, img, out, height,
+                           width, n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
+    else if (out_u8)
+        hipLaunchKernelGGL((gauss_sym_kernel<C, true, true, false>), dim3(blocks), dim3(256), 0, stream, img, out,
+                           height, width, n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
+    else if (symmetric && march_variant == 0)
         hipLaunchKernelGGL((gauss_sym_kernel<C, true>), dim3(blocks), dim3(256), 0, stream, img, out, height, width,
                            n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
     else if (symmetric)
         hipLaunchKernelGGL((gauss_sym_kernel<C, false>), dim3(blocks), dim3(256), 0, stream, img, out, height, width,
                            n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
     else
-        hipLaunchKernelGGL(gauss_march_kernel<C>, dim3(blocks), dim3(K::WPB * 64), 0, stream, img, out, height, width,
-                           n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
+        hipLaunchKernelGGL(gauss_march_kernel<C>, dim3(blocks), dim3(K::WPB * 64), 0, stream, img, (int16_t *)out,
+                           height, width, n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
     return hipGetLastError();
 }
 
 bool gaussian_march_supported(int center, int, int) { return center >= 1 && center <= 8; }
 
+static hipError_t launch_march_any(const uint8_t *img, void *out, int height, int width, int n_frames,
+                                   const GaussTaps &taps, hipStream_t stream, int out_u8)
+{
+    switch (taps.center) {
+    case 1: return launch_march_c<1>(img, out, height, width, n_frames, taps, stream, out_u8);
+    case 2: return launch_march_c<2>(img, out, height, width, n_frames, taps, stream, out_u8);
+    case 3: return launch_march_c<3>(img, out, height, width, n_frames, taps, stream, out_u8);
+    case 4: return launch_march_c<4>(img, out, height, width, n_frames, taps, stream, out_u8);
+    case 5: return launch_march_c<5>(img, out, height, width, n_frames, taps, stream, out_u8);
+    case 6: return launch_march_c<6>(img, out, height, width, n_frames, taps, stream, out_u8);
+    case 7: return launch_march_c<7>(img, out, height, width, n_frames, taps, stream, out_u8);
+    case 8: return launch_march_c<8>(img, out, height, width, n_frames, taps, stream, out_u8);
+    default: return hipErrorNotSupported;
+    }
+}
+
 hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, int width, int n_frames,
                                  const GaussTaps &taps, hipStream_t stream)
 {
-    switch (taps.center) {
-    case 1: return launch_march_c<1>(img, out, height, width, n_frames, taps, stream);
-    case 2: return launch_march_c<2>(img, out, height, width, n_frames, taps, stream);
-    case 3: return launch_march_c<3>(img, out, height, width, n_frames, taps, stream);
-    case 4: return launch_march_c<4>(img, out, height, width, n_frames, taps, stream);
-    case 5: return launch_march_c<5>(img, out, height, width, n_frames, taps, stream);
-    case 6: return launch_march_c<6>(img, out, height, width, n_frames, taps, stream);
-    case 7: return launch_march_c<7>(img, out, height, width, n_frames, taps, stream);
-    case 8: return launch_march_c<8>(img, out, height, width, n_frames, taps, stream);
-    default: return hipErrorNotSupported;
+    return launch_march_any(img, out, height, width, n_frames, taps, stream, 0);
+}
+
+bool gaussian_march_u8_supported(const GaussTaps &taps)
+{
+    if (taps.center < 1 || taps.center > 8 || march_variant != 0) return false;
+    for (int a = 1; a <= taps.center; a++)
+        if (std::memcmp(&taps.tap[taps.center - a], &taps.tap[taps.center + a], sizeof(float)) != 0) return false;
+    return true;
+}
+
+hipError_t launch_gaussian_march_u8(const uint8_t *img, uint8_t *out, int height, int width, int n_frames,
+                                    const GaussTaps &taps, hipStream_t stream, bool pk_convert)
+{
+    return launch_march_any(img, out, height, width, n_frames, taps, stream, pk_convert ? 2 : 1);
+}
+
+// ---- v_cvt_pk_u8_f32 against the truncating cast, for every float in [first_bits, last_bits] ---------------
+__global__ __launch_bounds__(256) void selftest_cvt_pk_u8_kernel(unsigned first_bits, unsigned last_bits,
+                                                                  unsigned long long *mismatches)
+{
+    unsigned long long bad = 0, worst = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long u = first_bits + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= last_bits;
+         u += stride) {
+        const float a = __uint_as_float((unsigned)u);
+        const int t = (int)a;                       // what the s16 kernels store (src/utils.cpp:62)
+        const unsigned want = t > 255 ? 255u : (unsigned)t; // a <= 256 here; 256.0 itself saturates
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t w = 0xa5a5a5a5u;
+            if (k == 0) asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(w) : "v"(a));
+            if (k == 1) asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(w) : "v"(a));
+            if (k == 2) asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(w) : "v"(a));
+            if (k == 3) asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(a));
+            const uint32_t expect = (0xa5a5a5a5u & ~(0xffu << (8 * k))) | (want << (8 * k));
+            ok = ok && w == expect;
+        }
+        if (!ok) {
+            bad++;
+            worst = u;
+        }
     }
+    if (bad) {
+        atomicAdd(mismatches, bad);
+        atomicMax(mismatches + 1, worst);
+    }
+}
+
+hipError_t launch_selftest_cvt_pk_u8(unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,
+                                     hipStream_t stream)
+{
+    hipLaunchKernelGGL(selftest_cvt_pk_u8_kernel, dim3(256 * 16), dim3(256), 0, stream, first_bits, last_bits,
+                       d_mismatches);
+    return hipGetLastError();
 }
 
 } // namespace canny

@@ -50,6 +50,16 @@ bool gaussian_march_supported(int center, int height, int width);
 hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, int width, int n_frames,
                                  const GaussTaps &taps, hipStream_t stream);
 
+// The same kernel storing the smoothed plane as BYTES ((short)(sum/count) lies in [0,255], src/utils.cpp:62):
+// half the store traffic, for the u8 form of the fused Sobel+NMS kernel.  Needs bit-symmetric taps and the default
+// march variant.  pk_convert: convert and pack with v_cvt_pk_u8_f32 instead of v_cvt_i32_f32 + shifts/ors.
+bool gaussian_march_u8_supported(const GaussTaps &taps);
+hipError_t launch_gaussian_march_u8(const uint8_t *img, uint8_t *out, int height, int width, int n_frames,
+                                    const GaussTaps &taps, hipStream_t stream, bool pk_convert);
+// v_cvt_pk_u8_f32 vs the truncating cast (saturated at 255) over float bit patterns [first_bits, last_bits]
+hipError_t launch_selftest_cvt_pk_u8(unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,
+                                     hipStream_t stream);
+
 // (S, c) bit-pattern pairs for which the interior waves divide by the full-window weight S with one
 // fma(a, c, a); returns the number of entries.  gaussian_set_fma_div(false) disables the shortcut
 // process-wide (A/B measurements only).
@@ -94,6 +104,15 @@ bool sobel_nms_classify_supported(int height, int width, int min_val);
 hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, int16_t *edges, uint64_t *strong, uint64_t *conn,
                                            const HystGeom &g, int min_val, int max_val, int edge_value,
                                            hipStream_t stream, int tune_seg = 0, const LaunchEvents &ev = {});
+
+// The two marching kernels reading the smoothed plane as BYTES (8 pixels per lane, LDS-staged planes only).
+bool sobel_nms_u8_input_supported();
+hipError_t launch_sobel_nms_march_u8in(const uint8_t *smoothed, int16_t *out, int height, int width, int n_frames,
+                                       hipStream_t stream, int tune_seg = 0, const LaunchEvents &ev = {});
+hipError_t launch_sobel_nms_classify_march_u8in(const uint8_t *smoothed, int16_t *edges, uint64_t *strong,
+                                                uint64_t *conn, const HystGeom &g, int min_val, int max_val,
+                                                int edge_value, hipStream_t stream, int tune_seg = 0,
+                                                const LaunchEvents &ev = {});
 
 // ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
 hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,

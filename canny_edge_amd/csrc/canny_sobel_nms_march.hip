@@ -111,6 +111,7 @@ using IC = std::integral_constant<int, N>;
 
 struct StripJob {
     const int16_t *fin;
+    const uint8_t *fin8; // IN_U8 kernels: the smoothed plane as bytes (its values lie in [0,255])
     int16_t *fout;
     int H, W, ybeg, yend, x0, lane;
     // PLANES only: this frame's hysteresis bit-planes (tile-major, see HystGeom) and the thresholds
@@ -141,9 +142,12 @@ __device__ __forceinline__ int max3_uniform(int a, int b, int c)
     return r;
 }
 
-template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP, bool LDS_PLANES>
+// IN_U8 (NP = 4 only): the smoothed plane arrives as bytes -- one 8-byte load per lane and row instead of a 16-byte
+// one; four v_perm_b32 spread the eight bytes into the four s16 pairs the rest of the kernel works on.
+template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP, bool LDS_PLANES, bool IN_U8 = false>
 __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_mem, const uint4 *edge_lut = nullptr)
 {
+    static_assert(!IN_U8 || NP == 4, "the u8 input form exists for 8 pixels per lane only");
     constexpr int PX = 2 * NP;
     const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend;
     const bool full8 = x0 >= 0 && x0 + PX - 1 < W; // all of this lane's pixels are inside the image
@@ -168,6 +172,25 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
 #pragma unroll
         for (int i = 0; i < NP; i++) p[i] = 0u;
         if (ROW_EDGE && (r < 0 || r >= H)) return; // wave-uniform: virtual rows are zero
+        if (IN_U8) {
+            const uint8_t *src8 = jb.fin8 + (size_t)r * W + x0;
+            if (!COL_EDGE || full8) {
+                uint2 b;
+                __builtin_memcpy(&b, src8, 8); // one 8-byte load
+                // selector bytes: 0-3 pick a byte of the source, 0x0c yields 0x00
+                p[0] = __builtin_amdgcn_perm(b.x, b.x, 0x0c010c00u);
+                p[1] = __builtin_amdgcn_perm(b.x, b.x, 0x0c030c02u);
+                p[NP > 2 ? 2 : 0] = __builtin_amdgcn_perm(b.y, b.y, 0x0c010c00u);
+                p[NP > 2 ? 3 : 1] = __builtin_amdgcn_perm(b.y, b.y, 0x0c030c02u);
+            } else if (x0 + PX - 1 >= 0 && x0 < W) {
+#pragma unroll
+                for (int e = 0; e < PX; e++) {
+                    int x = x0 + e;
+                    if (x >= 0 && x < W) p[e >> 1] |= (uint32_t)src8[e] << (16 * (e & 1));
+                }
+            }
+            return;
+        }
         const int16_t *src = jb.fin + (size_t)r * W + x0;
         if (!COL_EDGE || full8) {
             __builtin_memcpy(p, src, 4 * NP); // one 16-byte (8-byte) load
@@ -440,8 +463,8 @@ struct PlaneArgs { // PLANES instantiation only
     int tiles_x, tiles_y, lo1, hi1, edge_value;
 };
 
-template <bool PLANES, int NP, bool LDS_PLANES>
-__global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int16_t *__restrict__ in,
+template <bool PLANES, int NP, bool LDS_PLANES, bool IN_U8 = false>
+__global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const void *__restrict__ in,
                                                                        int16_t *__restrict__ out, int H, int W,
                                                                        int n_strips, int n_segs, int seg_rows,
                                                                        int total_waves, PlaneArgs pl)
@@ -484,7 +507,8 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
     jb.ybeg = g * seg_rows;
     jb.yend = min(H, jb.ybeg + seg_rows);
     jb.x0 = s * SnmCfg<NP>::SW + (jb.lane - 1) * SnmCfg<NP>::PX; // column of this lane's pixel 0
-    jb.fin = in + (size_t)f * H * W;
+    jb.fin = (const int16_t *)in + (size_t)f * H * W;
+    jb.fin8 = (const uint8_t *)in + (size_t)f * H * W;
     jb.fout = out + (size_t)f * H * W; // PLANES: the provisional edge map
     if (PLANES) {
         jb.edge_value = pl.edge_value;
@@ -501,14 +525,14 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const int
     const bool row_edge = (jb.ybeg < 2) || (jb.yend + 5 >= H);
     if (col_edge) {
         if (row_edge)
-            march_strip<true, true, PLANES, NP, LDS_PLANES>(jb, stage_mem, edge_lut);
+            march_strip<true, true, PLANES, NP, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
         else
-            march_strip<true, false, PLANES, NP, LDS_PLANES>(jb, stage_mem, edge_lut);
+            march_strip<true, false, PLANES, NP, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
     } else {
         if (row_edge)
-            march_strip<false, true, PLANES, NP, LDS_PLANES>(jb, stage_mem, edge_lut);
+            march_strip<false, true, PLANES, NP, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
         else
-            march_strip<false, false, PLANES, NP, LDS_PLANES>(jb, stage_mem, edge_lut);
+            march_strip<false, false, PLANES, NP, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
     }
 }
 
@@ -532,10 +556,12 @@ static void launch_timed(K kernel, dim3 grid, dim3 block, hipStream_t stream, co
         hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
 }
 
-static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const PlaneArgs *planes, int height, int width,
-                               int n_frames, hipStream_t stream, int tune_seg, const LaunchEvents &ev)
+static hipError_t launch_march(const void *smoothed, int16_t *out, const PlaneArgs *planes, int height, int width,
+                               int n_frames, hipStream_t stream, int tune_seg, const LaunchEvents &ev,
+                               bool in_u8 = false)
 {
     const int np = px_variant == 1 ? 2 : 4;
+    if (in_u8 && !(np == 4 && (!planes || plane_store_variant == 0))) return hipErrorNotSupported;
     const int sw = 62 * 2 * np;
     int n_strips = (width + sw - 1) / sw;
     // 64-row segments (6 % halo rows) beat longer ones at every batch size measured (64 x 4K: 0.462 ms against
@@ -552,7 +578,13 @@ static hipError_t launch_march(const int16_t *smoothed, int16_t *out, const Plan
     unsigned blocks = (unsigned)((waves + SNM_WPB - 1) / SNM_WPB);
     const PlaneArgs pl = planes ? *planes : PlaneArgs{};
     const dim3 grid(blocks), block(SNM_WPB * 64);
-    if (planes && np == 4 && plane_store_variant == 0)
+    if (in_u8 && planes)
+        launch_timed(sobel_nms_march_kernel<true, 4, true, true>, grid, block, stream, ev, smoothed, out, height, width,
+                     n_strips, n_segs, seg, (int)waves, pl);
+    else if (in_u8)
+        launch_timed(sobel_nms_march_kernel<false, 4, false, true>, grid, block, stream, ev, smoothed, out, height,
+                     width, n_strips, n_segs, seg, (int)waves, pl);
+    else if (planes && np == 4 && plane_store_variant == 0)
         launch_timed(sobel_nms_march_kernel<true, 4, true>, grid, block, stream, ev, smoothed, out, height, width,
                      n_strips, n_segs, seg, (int)waves, pl);
     else if (planes && np == 4)
@@ -581,9 +613,36 @@ bool sobel_nms_classify_supported(int height, int width, int min_val)
     return sobel_nms_march_supported(height, width) && width % 8 == 0 && min_val >= 1;
 }
 
+bool sobel_nms_u8_input_supported() { return px_variant == 0 && plane_store_variant == 0; }
+
+hipError_t launch_sobel_nms_march_u8in(const uint8_t *smoothed, int16_t *out, int height, int width, int n_frames,
+                                       hipStream_t stream, int tune_seg, const LaunchEvents &ev)
+{
+    return launch_march(smoothed, out, nullptr, height, width, n_frames, stream, tune_seg, ev, /*in_u8=*/true);
+}
+
+static hipError_t classify_march_any(const void *smoothed, bool in_u8, int16_t *edges, uint64_t *strong, uint64_t *conn,
+                                     const HystGeom &g, int min_val, int max_val, int edge_value, hipStream_t stream,
+                                     int tune_seg, const LaunchEvents &ev);
+
 hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, int16_t *edges, uint64_t *strong, uint64_t *conn,
                                            const HystGeom &g, int min_val, int max_val, int edge_value,
                                            hipStream_t stream, int tune_seg, const LaunchEvents &ev)
+{
+    return classify_march_any(smoothed, false, edges, strong, conn, g, min_val, max_val, edge_value, stream, tune_seg, ev);
+}
+
+hipError_t launch_sobel_nms_classify_march_u8in(const uint8_t *smoothed, int16_t *edges, uint64_t *strong,
+                                                uint64_t *conn, const HystGeom &g, int min_val, int max_val,
+                                                int edge_value, hipStream_t stream, int tune_seg,
+                                                const LaunchEvents &ev)
+{
+    return classify_march_any(smoothed, true, edges, strong, conn, g, min_val, max_val, edge_value, stream, tune_seg, ev);
+}
+
+static hipError_t classify_march_any(const void *smoothed, bool in_u8, int16_t *edges, uint64_t *strong, uint64_t *conn,
+                                     const HystGeom &g, int min_val, int max_val, int edge_value, hipStream_t stream,
+                                     int tune_seg, const LaunchEvents &ev)
 {
     if (!sobel_nms_classify_supported(g.height, g.width, min_val)) return hipErrorNotSupported;
     if (edge_value < 0 || edge_value > 32767) return hipErrorInvalidValue;
@@ -598,7 +657,7 @@ hipError_t launch_sobel_nms_classify_march(const int16_t *smoothed, int16_t *edg
     pl.lo1 = lo - 1;
     pl.hi1 = (hi > lo ? hi : lo) - 1;
     pl.edge_value = edge_value;
-    return launch_march(smoothed, edges, &pl, g.height, g.width, g.n_frames, stream, tune_seg, ev);
+    return launch_march(smoothed, edges, &pl, g.height, g.width, g.n_frames, stream, tune_seg, ev, in_u8);
 }
 
 } // namespace canny

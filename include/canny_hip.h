@@ -98,6 +98,11 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "gaussian_fma_div": 1 (default) / 0 -- single-fma division by the full-window weight (process-wide)
  *   "fuse_classify": 1 (default) / 0 -- canny(): the Sobel+NMS kernel writes the hysteresis bit-planes itself
  *                    (used when width % 8 == 0 and min_val >= 1; otherwise the separate kernels run)
+ *   "smoothed_u8": 0 (default) / 1 / 2 -- canny(): the smoothed plane between the Gaussian and the fused Sobel+NMS
+ *                    kernel is stored as bytes instead of shorts ((short)(sum/count) lies in [0,255],
+ *                    src/utils.cpp:62): 5.25 instead of 7.25 algorithmic bytes per pixel through HBM; 2 converts with
+ *                    v_cvt_pk_u8_f32.  Used when the fused path and the marching Gaussian apply, else ignored.
+ *                    Same results bit for bit
  *   "overlap_hysteresis": 0 (default) / 1 -- canny() on 16 or more frames: the propagation sweeps of the first half
  *                    of the batch run on a second stream beside the Sobel+NMS kernel of the second half
  *                    (measured 1.5 % slower on 128 x 4K, kept for A/B)
@@ -205,6 +210,13 @@ int canny_hip_dev_nms(canny_hip_ctx *ctx, const short *d_magnitude, const short 
  * HBM (4 algorithmic bytes per pixel).  d_smoothed must lie in [0,255] (gaussian output). */
 int canny_hip_dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int height, int width, int n_frames,
                             short *d_nms);
+/* The two kernels of canny()'s "smoothed_u8" path on their own (tests, A/B): the Gaussian storing bytes
+ * (pk_convert != 0: v_cvt_pk_u8_f32), and the fused Sobel+NMS reading them (3 algorithmic bytes per pixel).
+ * CANNY_HIP_ERR_UNSUPPORTED where the marching kernels do not apply (window > 17, asymmetric taps, A/B variants). */
+int canny_hip_dev_gaussian_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int height, int width,
+                              int n_frames, unsigned char *d_result, int pk_convert);
+int canny_hip_dev_sobel_nms_u8in(canny_hip_ctx *ctx, const unsigned char *d_smoothed, int height, int width,
+                                 int n_frames, short *d_nms);
 /* In place.  Blocks the host until propagation has converged (it polls a device flag). */
 int canny_hip_dev_hysteresis(canny_hip_ctx *ctx, short *d_edge_candidates, int height, int width, int n_frames,
                              int min_val, int max_val);
@@ -251,6 +263,9 @@ int canny_hip_selftest_div_fma(canny_hip_ctx *ctx, float divisor, float c, unsig
                                float *largest_mismatching_dividend);
 /* Entry `index` of the built-in (divisor, c) table the kernels use; CANNY_HIP_ERR_INVALID past the end. */
 int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c);
+/* v_cvt_pk_u8_f32 (the "smoothed_u8" = 2 conversion) against the truncating cast saturated at 255, for every float
+ * in [0, 256], all four byte positions. */
+int canny_hip_selftest_cvt_pk_u8(canny_hip_ctx *ctx, unsigned long long *mismatches, float *largest_mismatching_input);
 /* Host-only: number of CPUs in a sysfs-style list ("0-3,8,10-11" -> 7; 0 if malformed) -- the parser behind the
  * sharder's NUMA binding. */
 int canny_hip_selftest_cpulist_count(const char *text);

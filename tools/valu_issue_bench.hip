@@ -414,6 +414,119 @@ DEF_KERNEL(alignbit_b32, REP16, I_ALIGNBIT, "")
 DEF_KERNEL(mul_i32_i24, REP16, I_MUL_I32_I24, "")
 DEF_KERNEL(cvt_pk_u8_f32, REP16, I_CVT_PK_U8, "")
 
+
+// ---- round 2, second batch: what makes an instruction "slow class", and what do switches between classes cost? ----
+#define I_MAX_F32(d) "v_max_f32 %" #d ", %" #d ", %16\n\t"
+#define I_SUB_F32(d) "v_sub_f32 %" #d ", %" #d ", %16\n\t"
+#define I_OR_B32(d) "v_or_b32 %" #d ", %" #d ", %16\n\t"
+#define I_XOR_B32(d) "v_xor_b32 %" #d ", %" #d ", %16\n\t"
+#define I_MIN_U32(d) "v_min_u32 %" #d ", %" #d ", %16\n\t"
+#define I_ASHRREV(d) "v_ashrrev_i32 %" #d ", 3, %" #d "\n\t"
+#define I_BFE_U32(d) "v_bfe_u32 %" #d ", %" #d ", 8, 8\n\t"
+#define I_LSHL_OR(d) "v_lshl_or_b32 %" #d ", %" #d ", 16, %16\n\t"
+#define I_ADD3(d) "v_add3_u32 %" #d ", %" #d ", %16, %17\n\t"
+#define I_BFI(d) "v_bfi_b32 %" #d ", %16, %17, %" #d "\n\t"
+#define I_MED3_I32(d) "v_med3_i32 %" #d ", %" #d ", %16, %17\n\t"
+#define I_CVT_F32_U32(d) "v_cvt_f32_u32 %" #d ", %" #d "\n\t"
+#define I_SUBREV_U32(d) "v_subrev_u32 %" #d ", %" #d ", %16\n\t"
+#define I_MUL_U32_U24(d) "v_mul_u32_u24 %" #d ", %" #d ", %16\n\t"
+#define I_PK_ADD_U16(d) "v_pk_add_u16 %" #d ", %" #d ", %16\n\t"
+#define I_MAX_U16(d) "v_max_u16 %" #d ", %" #d ", %16\n\t"
+#define I_SWIZZLE(d) "ds_swizzle_b32 %" #d ", %" #d " offset:swizzle(SWAP,1)\n\t"
+#define I_BPERMUTE(d) "ds_bpermute_b32 %" #d ", %19, %" #d "\n\t"
+#define I_CMP_CNDMASK(d) "v_cmp_gt_i32 vcc, %" #d ", %16\n\tv_cndmask_b32 %" #d ", %17, %" #d ", vcc\n\t"
+#define I_CMP_NOP_CNDMASK(d) "v_cmp_gt_i32 vcc, %" #d ", %16\n\ts_nop 1\n\tv_cndmask_b32 %" #d ", %17, %" #d ", vcc\n\t"
+#define I_CNDMASK_E64(d) "v_cndmask_b32_e64 %" #d ", %16, %" #d ", s[20:21]\n\t"
+#define I_CMPE64_CNDMASK(d) "v_cmp_gt_i32_e64 s[20:21], %" #d ", %16\n\ts_nop 1\n\tv_cndmask_b32_e64 %" #d ", %17, %" #d ", s[20:21]\n\t"
+#define I_CMP_SDST(d) "v_cmp_gt_i32_e64 s[20:21], %" #d ", %16\n\t"
+#define I_ADDC(d) "v_addc_co_u32 %" #d ", vcc, %" #d ", %16, vcc\n\t"
+#define I_MUL_SGPR(d) "v_mul_f32 %" #d ", %18, %" #d "\n\t"
+DEF_KERNEL(max_f32, REP16, I_MAX_F32, "")
+DEF_KERNEL(sub_f32, REP16, I_SUB_F32, "")
+DEF_KERNEL(or_b32, REP16, I_OR_B32, "")
+DEF_KERNEL(xor_b32, REP16, I_XOR_B32, "")
+DEF_KERNEL(min_u32, REP16, I_MIN_U32, "")
+DEF_KERNEL(ashrrev_i32, REP16, I_ASHRREV, "")
+DEF_KERNEL(bfe_u32, REP16, I_BFE_U32, "")
+DEF_KERNEL(lshl_or_b32, REP16, I_LSHL_OR, "")
+DEF_KERNEL(add3_u32, REP16, I_ADD3, "")
+DEF_KERNEL(bfi_b32, REP16, I_BFI, "")
+DEF_KERNEL(med3_i32, REP16, I_MED3_I32, "")
+DEF_KERNEL(cvt_f32_u32, REP16, I_CVT_F32_U32, "")
+DEF_KERNEL(subrev_u32, REP16, I_SUBREV_U32, "")
+DEF_KERNEL(mul_u32_u24, REP16, I_MUL_U32_U24, "")
+DEF_KERNEL(pk_add_u16, REP16, I_PK_ADD_U16, "")
+DEF_KERNEL(max_u16, REP16, I_MAX_U16, "")
+DEF_KERNEL(ds_swizzle, REP16, I_SWIZZLE, WAIT_LGKM)
+DEF_KERNEL(ds_bpermute, REP16, I_BPERMUTE, WAIT_LGKM)
+DEF_KERNEL(cmp_cndmask, REP16, I_CMP_CNDMASK, "")
+DEF_KERNEL(cmp_nop_cndmask, REP16, I_CMP_NOP_CNDMASK, "")
+DEF_KERNEL(addc_only, REP16, I_ADDC, "")
+DEF_KERNEL(mul_f32_sgpr, REP16, I_MUL_SGPR, "")
+// SGPR-pair masks: s[20:21] is clobbered explicitly
+#define OPERANDS_S20                                                                                              \
+    : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), \
+      "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])                    \
+    : "v"(s0), "v"(s1), "s"(sc), "v"(lds_addr)                                                                    \
+    : "vcc", "memory", "s20", "s21"
+#define DEF_KERNEL_S20(NAME, BODY)                                                                   \
+    __global__ void __launch_bounds__(1024) k_##NAME(Stamp *stamps, unsigned *sink, int iters)       \
+    {                                                                                                \
+        extern __shared__ unsigned lds[];                                                            \
+        unsigned a[16];                                                                              \
+        for (int i = 0; i < 16; i++) a[i] = threadIdx.x * 16 + i;                                    \
+        unsigned s0 = threadIdx.x | 1u, s1 = threadIdx.x * 3u + 7u;                                  \
+        unsigned sc = (unsigned)iters | 3u;                                                          \
+        unsigned lds_addr = (threadIdx.x & 63u) * 4u;                                                \
+        for (unsigned i = threadIdx.x; i < 2048; i += blockDim.x) lds[i] = i;                        \
+        __syncthreads();                                                                             \
+        asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20", "s21");                                 \
+        unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                    \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                        \
+        for (int it = 0; it < iters; it++) {                                                         \
+            asm volatile(BODY OPERANDS_S20);                                                         \
+        }                                                                                            \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                        \
+        unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                    \
+        unsigned acc = 0;                                                                            \
+        for (int i = 0; i < 16; i++) acc ^= a[i];                                                    \
+        if (acc == 0x12345u) sink[0] = acc;                                                          \
+        if ((threadIdx.x & 63) == 0) {                                                               \
+            unsigned hw, xcc;                                                                        \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                         \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                       \
+            Stamp s{t0, t1, r0, r1, hw, xcc};                                                        \
+            stamps[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = s;                           \
+        }                                                                                            \
+    }
+DEF_KERNEL_S20(cndmask_e64_sgpr, REP16(I_CNDMASK_E64) REP16(I_CNDMASK_E64) REP16(I_CNDMASK_E64) REP16(I_CNDMASK_E64))
+DEF_KERNEL_S20(cmp_e64_nop_cndmask_e64, REP16(I_CMPE64_CNDMASK) REP16(I_CMPE64_CNDMASK) REP16(I_CMPE64_CNDMASK) REP16(I_CMPE64_CNDMASK))
+DEF_KERNEL_S20(cmp_e64_sdst, REP16(I_CMP_SDST) REP16(I_CMP_SDST) REP16(I_CMP_SDST) REP16(I_CMP_SDST))
+// DPP grouped: 52 plain adds then 12 DPP adds (the Gaussian mix's ratio), and 2 groups of 26 + 6
+#define PLAIN4(a, b, c, d) "v_add_f32 %" #a ", %" #a ", %16\n\tv_mul_f32 %" #b ", %" #b ", %17\n\tv_add_f32 %" #c ", %" #c ", %17\n\tv_add_f32 %" #d ", %" #d ", %16\n\t"
+#define DPP4(a, b, c, d)                                                         \
+    "v_add_f32_dpp %" #a ", %16, %" #a " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %" #b ", %17, %" #b " wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %" #c ", %16, %" #c " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %" #d ", %17, %" #d " wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+#define P13 PLAIN4(0, 1, 2, 3) PLAIN4(4, 5, 6, 7) PLAIN4(8, 9, 10, 11) PLAIN4(12, 13, 14, 15) PLAIN4(0, 5, 10, 15) PLAIN4(1, 6, 11, 12) PLAIN4(2, 7, 8, 13) PLAIN4(3, 4, 9, 14) PLAIN4(0, 1, 2, 3) PLAIN4(4, 5, 6, 7) PLAIN4(8, 9, 10, 11) PLAIN4(12, 13, 14, 15) PLAIN4(0, 5, 10, 15)
+DEF_KERNEL1(dpp_grouped_52_12, P13 DPP4(0, 1, 2, 3) DPP4(4, 5, 6, 7) DPP4(8, 9, 10, 11))
+// spread: one DPP add after every 4-5 plain ones (13 groups of 4 plain, 12 DPP singles)
+#define D1(a) "v_add_f32_dpp %" #a ", %16, %" #a " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+DEF_KERNEL1(dpp_spread_52_12, PLAIN4(0, 1, 2, 3) D1(4) PLAIN4(5, 6, 7, 8) D1(9) PLAIN4(10, 11, 12, 13) D1(14) PLAIN4(15, 0, 1, 2) D1(3) PLAIN4(4, 5, 6, 7) D1(8) PLAIN4(9, 10, 11, 12) D1(13) PLAIN4(14, 15, 0, 1) D1(2) PLAIN4(3, 4, 5, 6) D1(7) PLAIN4(8, 9, 10, 11) D1(12) PLAIN4(13, 14, 15, 0) D1(1) PLAIN4(2, 3, 4, 5) D1(6) PLAIN4(7, 8, 9, 10) D1(11) PLAIN4(12, 13, 14, 15))
+// SGPR operands: every 4th instruction multiplies by an SGPR (taps as kernel arguments) vs all-VGPR
+#define SG4(a, b, c, d) "v_add_f32 %" #a ", %" #a ", %16\n\tv_mul_f32 %" #b ", %18, %" #b "\n\tv_add_f32 %" #c ", %" #c ", %17\n\tv_add_f32 %" #d ", %" #d ", %16\n\t"
+DEF_KERNEL1(sgpr_every_4th, SG4(0, 1, 2, 3) SG4(4, 5, 6, 7) SG4(8, 9, 10, 11) SG4(12, 13, 14, 15) SG4(0, 5, 10, 15) SG4(1, 6, 11, 12) SG4(2, 7, 8, 13) SG4(3, 4, 9, 14) SG4(0, 1, 2, 3) SG4(4, 5, 6, 7) SG4(8, 9, 10, 11) SG4(12, 13, 14, 15) SG4(0, 5, 10, 15) SG4(1, 6, 11, 12) SG4(2, 7, 8, 13) SG4(3, 4, 9, 14))
+// cvt every 8th
+#define CV8(a, b, c, d, e, f, g, h) PLAIN4(a, b, c, d) "v_add_f32 %" #e ", %" #e ", %16\n\tv_mul_f32 %" #f ", %" #f ", %17\n\tv_add_f32 %" #g ", %" #g ", %17\n\tv_cvt_i32_f32 %" #h ", %" #h "\n\t"
+DEF_KERNEL1(cvt_every_8th, CV8(0, 1, 2, 3, 4, 5, 6, 7) CV8(8, 9, 10, 11, 12, 13, 14, 15) CV8(0, 1, 2, 3, 4, 5, 6, 7) CV8(8, 9, 10, 11, 12, 13, 14, 15) CV8(0, 1, 2, 3, 4, 5, 6, 7) CV8(8, 9, 10, 11, 12, 13, 14, 15) CV8(0, 1, 2, 3, 4, 5, 6, 7) CV8(8, 9, 10, 11, 12, 13, 14, 15))
+// LDS shuffles beside plain VALU: 1 ds_swizzle + 3 plain adds
+#define SW4(a, b, c, d) "ds_swizzle_b32 %" #a ", %" #a " offset:swizzle(SWAP,1)\n\tv_mul_f32 %" #b ", %" #b ", %17\n\tv_add_f32 %" #c ", %" #c ", %17\n\tv_add_f32 %" #d ", %" #d ", %16\n\t"
+DEF_KERNEL1(swizzle_plus_3_plain, SW4(0, 1, 2, 3) SW4(4, 5, 6, 7) SW4(8, 9, 10, 11) SW4(12, 13, 14, 15) SW4(0, 5, 10, 15) SW4(1, 6, 11, 12) SW4(2, 7, 8, 13) SW4(3, 4, 9, 14) SW4(0, 1, 2, 3) SW4(4, 5, 6, 7) SW4(8, 9, 10, 11) SW4(12, 13, 14, 15) SW4(0, 5, 10, 15) SW4(1, 6, 11, 12) SW4(2, 7, 8, 13) SW4(3, 4, 9, 14) "s_waitcnt lgkmcnt(0)\n\t")
+// 1 ds_swizzle + 7 plain
+#define SW8(a, b, c, d, e, f, g, h) "ds_swizzle_b32 %" #a ", %" #a " offset:swizzle(SWAP,1)\n\tv_mul_f32 %" #b ", %" #b ", %17\n\tv_add_f32 %" #c ", %" #c ", %17\n\tv_add_f32 %" #d ", %" #d ", %16\n\t" PLAIN4(e, f, g, h)
+DEF_KERNEL1(swizzle_plus_7_plain, SW8(0, 1, 2, 3, 4, 5, 6, 7) SW8(8, 9, 10, 11, 12, 13, 14, 15) SW8(0, 1, 2, 3, 4, 5, 6, 7) SW8(8, 9, 10, 11, 12, 13, 14, 15) SW8(0, 1, 2, 3, 4, 5, 6, 7) SW8(8, 9, 10, 11, 12, 13, 14, 15) SW8(0, 1, 2, 3, 4, 5, 6, 7) SW8(8, 9, 10, 11, 12, 13, 14, 15) "s_waitcnt lgkmcnt(0)\n\t")
+
 typedef void (*kernel_t)(Stamp *, unsigned *, int);
 struct Test {
     const char *name;
@@ -484,6 +597,38 @@ static const Test kTests[] = {
     {"Gaussian mix: 64 VALU + 6 ds_read2st64", k_gauss_mix, 64, "per VALU instruction"},
     {"Gaussian mix without the LDS reads", k_gauss_mix_nods, 64, ""},
     {"Gaussian mix, DPP adds made plain, no LDS", k_gauss_mix_plain, 64, ""},
+    // ---- second batch (index 62 on) ----
+    {"v_max_f32", k_max_f32, 64, ""},
+    {"v_sub_f32", k_sub_f32, 64, ""},
+    {"v_or_b32", k_or_b32, 64, ""},
+    {"v_xor_b32", k_xor_b32, 64, ""},
+    {"v_min_u32", k_min_u32, 64, ""},
+    {"v_ashrrev_i32", k_ashrrev_i32, 64, ""},
+    {"v_bfe_u32", k_bfe_u32, 64, ""},
+    {"v_lshl_or_b32", k_lshl_or_b32, 64, ""},
+    {"v_add3_u32", k_add3_u32, 64, ""},
+    {"v_bfi_b32", k_bfi_b32, 64, "select without a lane mask"},
+    {"v_med3_i32", k_med3_i32, 64, ""},
+    {"v_cvt_f32_u32", k_cvt_f32_u32, 64, ""},
+    {"v_subrev_u32", k_subrev_u32, 64, ""},
+    {"v_mul_u32_u24", k_mul_u32_u24, 64, ""},
+    {"v_pk_add_u16", k_pk_add_u16, 64, ""},
+    {"v_max_u16", k_max_u16, 64, ""},
+    {"v_mul_f32 v,s,v (SGPR src)", k_mul_f32_sgpr, 64, ""},
+    {"v_addc_co_u32 (VCC in/out)", k_addc_only, 64, ""},
+    {"v_cmp + v_cndmask (vcc), per PAIR", k_cmp_cndmask, 64, "per pair"},
+    {"v_cmp + s_nop 1 + v_cndmask (vcc), per TRIPLE", k_cmp_nop_cndmask, 64, "per triple"},
+    {"v_cndmask_b32_e64 with SGPR-pair mask", k_cndmask_e64_sgpr, 64, ""},
+    {"v_cmp_e64 sdst + s_nop 1 + v_cndmask_e64, per TRIPLE", k_cmp_e64_nop_cndmask_e64, 64, "per triple"},
+    {"v_cmp_gt_i32_e64 s[20:21]", k_cmp_e64_sdst, 64, ""},
+    {"ds_swizzle_b32", k_ds_swizzle, 64, ""},
+    {"ds_bpermute_b32", k_ds_bpermute, 64, ""},
+    {"1 ds_swizzle + 3 plain VALU", k_swizzle_plus_3_plain, 64, "per instruction of the mix"},
+    {"1 ds_swizzle + 7 plain VALU", k_swizzle_plus_7_plain, 64, "per instruction of the mix"},
+    {"52 plain then 12 DPP adds (grouped)", k_dpp_grouped_52_12, 64, ""},
+    {"52 plain, 12 DPP adds spread singly", k_dpp_spread_52_12, 64, ""},
+    {"plain VALU, every 4th with an SGPR operand", k_sgpr_every_4th, 64, ""},
+    {"plain VALU, every 8th a v_cvt_i32_f32", k_cvt_every_8th, 64, ""},
 };
 
 struct Result {
@@ -579,7 +724,10 @@ int main(int argc, char **argv)
     for (auto &sh : kShapes) std::printf(" | %-25d", sh.waves_per_simd);
     std::printf("\n");
     std::string json = "{\n  \"_shapes_waves_per_simd\": [1, 2, 3, 4, 6, 8],\n";
+    const int first = argc > 2 ? std::atoi(argv[2]) : 0;
+    int index = 0;
     for (const Test &t : kTests) {
+        if (index++ < first) continue;
         Result r[kNumShapes];
         for (int i = 0; i < kNumShapes; i++) r[i] = run(t, kShapes[i], iters, d_stamps, d_sink, cus);
         std::printf("%-42s", t.name);

@@ -22,7 +22,8 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcanny_hip.so")
+# CANNY_HIP_LIB: another build of the same library (A/B measurements of kernel variants, tools/ab_stage_times.py)
+LIB_PATH = os.environ.get("CANNY_HIP_LIB") or os.path.join(_HERE, "libcanny_hip.so")
 
 OK = 0
 STAGE_GAUSSIAN, STAGE_SOBEL_NMS, STAGE_HYST_CLASSIFY, STAGE_HYST_PROPAGATE, STAGE_HYST_FINALIZE, \
@@ -44,7 +45,7 @@ EXPORTS = (
     "canny_hip_selftest_mag_angle", "canny_hip_selftest_div", "canny_hip_selftest_div_fma",
     "canny_hip_selftest_div_fma_table", "canny_hip_canny_multi_gpu_u8", "canny_hip_multi_gpu_set_option",
     "canny_hip_multi_gpu_release", "canny_hip_device_local_cpus", "canny_hip_selftest_cpulist_count",
-    "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in", "canny_hip_selftest_cvt_pk_u8",
+    "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -112,9 +113,8 @@ def load() -> C.CDLL:
         "canny_hip_dev_nms": ([p, p, p, i, i, i, p], i),
         "canny_hip_dev_sobel_nms": ([p, p, i, i, i, p], i),
         "canny_hip_dev_hysteresis": ([p, p, i, i, i, i, i], i),
-        "canny_hip_dev_gaussian_u8": ([p, p, f, i, i, i, p, i], i),
+        "canny_hip_dev_gaussian_u8": ([p, p, f, i, i, i, p], i),
         "canny_hip_dev_sobel_nms_u8in": ([p, p, i, i, i, p], i),
-        "canny_hip_selftest_cvt_pk_u8": ([p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
         "canny_hip_dev_canny": ([p, p, f, i, i, i, i, i, p], i),
         "canny_hip_dev_canny_stream": ([p, p, f, i, i, i, i, i, p], i),
         "canny_hip_dev_canny_stream_flush": ([p], i),
@@ -379,19 +379,14 @@ class Context:
         self._check(self._L.canny_hip_dev_sobel_nms(self._h, C.c_void_p(d_smoothed), h, w, n, C.c_void_p(d_out)),
                     "dev_sobel_nms")
 
-    def dev_gaussian_u8(self, d_img: int, sigma: float, h: int, w: int, n: int, d_out: int, pk_convert: bool = False):
+    def dev_gaussian_u8(self, d_img: int, sigma: float, h: int, w: int, n: int, d_out: int):
         """Gaussian storing the smoothed plane as bytes (the "smoothed_u8" path of canny())."""
-        self._check(self._L.canny_hip_dev_gaussian_u8(self._h, C.c_void_p(d_img), sigma, h, w, n, C.c_void_p(d_out),
-                                                      int(pk_convert)), "dev_gaussian_u8")
+        self._check(self._L.canny_hip_dev_gaussian_u8(self._h, C.c_void_p(d_img), sigma, h, w, n, C.c_void_p(d_out)),
+                    "dev_gaussian_u8")
 
     def dev_sobel_nms_u8in(self, d_smoothed: int, h: int, w: int, n: int, d_out: int):
         self._check(self._L.canny_hip_dev_sobel_nms_u8in(self._h, C.c_void_p(d_smoothed), h, w, n, C.c_void_p(d_out)),
                     "dev_sobel_nms_u8in")
-
-    def selftest_cvt_pk_u8(self) -> Tuple[int, float]:
-        bad, worst = C.c_ulonglong(0), C.c_float(0.0)
-        self._check(self._L.canny_hip_selftest_cvt_pk_u8(self._h, C.byref(bad), C.byref(worst)), "selftest_cvt_pk_u8")
-        return bad.value, worst.value
 
     def dev_hysteresis(self, d_cand: int, h: int, w: int, n: int, min_val: int, max_val: int):
         self._check(self._L.canny_hip_dev_hysteresis(self._h, C.c_void_p(d_cand), h, w, n, min_val, max_val),

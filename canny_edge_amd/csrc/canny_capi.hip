@@ -114,15 +114,20 @@ struct canny_hip_ctx {
     int tune_sobel_seg = 0;  // A/B knob of the marching Sobel+NMS kernel: rows per segment, 0 = automatic
     int fuse_classify = 1;   // canny(): Sobel+NMS emits the hysteresis bit-planes directly when it can
     // canny(): the smoothed plane between the Gaussian and the fused Sobel+NMS kernel as bytes (its values lie in
-    // [0,255], src/utils.cpp:62): 0 = s16 plane, 1 = u8 plane, 2 = u8 plane converted with v_cvt_pk_u8_f32
+    // [0,255], src/utils.cpp:62): 0 = s16 plane, 1 = u8 plane
     int smoothed_u8 = 0;
+    // canny(): after the two batch-wide sweeps, one launch with a workgroup per frame finishes the propagation
+    // (launch_hyst_tail): no further launches, no host round trip, the call returns without waiting.
+    // 1 (default) = for frames of up to kTailMaxTiles tiles, 0 = never (the multi-launch scheme with its poll)
+    int hyst_tail = 1;
+    bool hyst_iters_async = false; // last_hyst_iters has to be fetched from flags[0] (the tail path does not poll)
     // canny_hip_canny_batch: number of pipelines (host threads, each with an H2D, a compute and a D2H stream and a
     // ring of chunk slots) that each take every n-th chunk, and the chunk size (megabytes of input, or frames).
     // 0 = automatic, see canny_batch_impl.
     int batch_workers = 0;
     int batch_chunk_mb = 0;
     int batch_chunk_frames = 0;
-    int batch_pipe_mode = 0; // A/B: 0 = three streams per pipeline, 1 = everything in order on one stream per pipeline
+    int batch_pipe_mode = 0; // 0 = automatic, 1 = three streams per pipeline, 2 = one in-order stream per pipeline
     // the pipelines live as long as the context: creating a sub-context with its streams and allocating its
     // staging costs ~10 ms per call, a sixth of a 1024 x 1080p batch
     struct BatchPipe;
@@ -167,10 +172,15 @@ struct canny_hip_ctx {
 //   s_d2h:    d_out / d_out8 -> host              (ev_d2h; waits for ev_comp)
 // so that the upload of chunk j+1, the kernels of chunk j and the download of chunk j-1 are in flight together and
 // neither DMA engine waits for a host thread.  Pageable caller buffers go through the slot's pinned staging.
+// HIP multiplexes a process's streams onto a handful of hardware queues (4 by default, GPU_MAX_HW_QUEUES), and
+// streams that share a queue serialise: measured on 128 x 4K, the same pipeline ran at 25.3 Gpix/s with four streams
+// alive in the process and at 16.7 with six.  So streams are created sparingly: pipeline 0 computes on the parent
+// context itself (its stream is idle during a batch call), the copy streams exist only in three-stream mode.
 struct canny_hip_ctx::BatchPipe {
     static constexpr int kSlots = 3;
-    canny_hip_ctx *sub = nullptr;
-    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    canny_hip_ctx *sub = nullptr; // compute context: the parent itself for pipeline 0, an owned sub-context otherwise
+    bool owns_sub = false;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr; // three-stream mode only, created on first use
     struct Slot {
         DevBuf d_in, d_out, d_out8;
         PinBuf pin_in, pin_out;
@@ -286,7 +296,7 @@ bool gaussian_u8_possible(const canny_hip_ctx *ctx, const GaussTaps &taps, int h
            gaussian_march_u8_supported(taps) && sobel_nms_u8_input_supported();
 }
 
-// u8_mode: 0 = s16 plane in d_out; 1 / 2 = u8 plane in d_out (2: v_cvt_pk_u8_f32), only if gaussian_u8_possible()
+// u8_mode: 0 = s16 plane in d_out; 1 = u8 plane in d_out, only if gaussian_u8_possible()
 int dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int h, int w, int n, void *d_out_any,
                  int u8_mode = 0)
 {
@@ -297,7 +307,7 @@ int dev_gaussian(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, in
     StageTimer tm(ctx, CANNY_HIP_STAGE_GAUSSIAN);
     if (u8_mode) {
         if (!gaussian_u8_possible(ctx, taps, h, w)) return CANNY_HIP_ERR_UNSUPPORTED;
-        HIP_TRY(ctx, launch_gaussian_march_u8(d_img, (uint8_t *)d_out_any, h, w, n, taps, ctx->stream, u8_mode == 2));
+        HIP_TRY(ctx, launch_gaussian_march_u8(d_img, (uint8_t *)d_out_any, h, w, n, taps, ctx->stream));
         return CANNY_HIP_OK;
     }
     // The marching kernel divides through a precomputed reciprocal, which equals the IEEE quotient for every
@@ -364,6 +374,7 @@ int prepare_hyst(canny_hip_ctx *ctx, const HystGeom &g, bool zero_pad)
 // If the flag says "not converged" (rare) the consumer simply runs again behind the next chunk.
 // edges != nullptr: the sweeps write the pixels they promote straight into that edge map (which must already
 // hold the strong pixels); there is then nothing left for a consumer to do.
+constexpr int kTailMaxTiles = 4096; // per frame (a 4K frame has 2040): beyond that one workgroup per frame is too few
 constexpr int kSweepChunk = 8;
 constexpr int kMaxSweeps = 1 << 22;
 
@@ -429,6 +440,7 @@ int run_propagation(canny_hip_ctx *ctx, const HystGeom &g, bool speculative, Con
 {
     PropLane L = main_lane(ctx, g, edges, edge_value);
     ctx->last_hyst_iters = 0;
+    ctx->hyst_iters_async = false;
     int rc;
     do {
         if ((rc = lane_launch_chunk(ctx, L))) return rc;
@@ -563,6 +575,19 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
             HIP_TRY(ctx, fused_sobel(sm, d_edges, S, C, g, edge_value, tm.launch_events()));
         }
         // d_edges now holds the strong pixels; the sweeps add every pixel they promote: no finalize pass
+        if (ctx->hyst_tail && g.tiles_x * g.tiles_y <= kTailMaxTiles) {
+            // two batch-wide sweeps (all tiles; then the tiles those re-scheduled), then one workgroup per frame
+            // runs the rest to convergence: everything is queued, nothing is waited for
+            StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_PROPAGATE);
+            unsigned *sched = (unsigned *)ctx->stamps.p, *flags = (unsigned *)ctx->flags.p;
+            HIP_TRY(ctx, launch_hyst_propagate(S, C, sched, flags, 0, g, ctx->stream, d_edges, edge_value));
+            HIP_TRY(ctx, launch_hyst_propagate(S, C, sched, flags, 1, g, ctx->stream, d_edges, edge_value,
+                                               /*to_frame_queues=*/true));
+            HIP_TRY(ctx, launch_hyst_tail(S, C, sched, flags, 2, g, ctx->stream, d_edges, edge_value));
+            ctx->hyst_iters_async = true;
+            return CANNY_HIP_OK;
+        }
+        ctx->hyst_iters_async = false;
         return run_propagation(ctx, g, /*speculative=*/false, []() -> int { return CANNY_HIP_OK; }, d_edges, edge_value);
     }
     if ((rc = dev_sobel_nms(ctx, sm, h, w, n, d_edges))) return rc;
@@ -601,8 +626,11 @@ int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma
 {
     if (h < 2 || w < 2) return CANNY_HIP_ERR_UNSUPPORTED;
     if (hysteresis_order_dependent(lo, hi)) return CANNY_HIP_ERR_DOMAIN;
-    if (!(ctx->fuse_classify && ctx->sobel_nms_path != 1 && sobel_nms_classify_supported(h, w, lo))) {
-        int rc = finish_pending(ctx); // shapes the fused kernel does not take: plain call, nothing left in flight
+    if (!(ctx->fuse_classify && ctx->sobel_nms_path != 1 && sobel_nms_classify_supported(h, w, lo)) ||
+        (ctx->hyst_tail && make_hyst_geom(h, w, n).tiles_x * make_hyst_geom(h, w, n).tiles_y <= kTailMaxTiles)) {
+        // shapes the fused kernel does not take: plain call, nothing left in flight.  With the per-frame tail kernel
+        // a plain call does not wait for anything either, so there is nothing to defer.
+        int rc = finish_pending(ctx);
         return rc ? rc : dev_canny(ctx, d_img, sigma, lo, hi, h, w, n, d_edges);
     }
     HIP_TRY(ctx, ctx->smoothed.ensure(npx(h, w, n) * sizeof(short)));
@@ -675,29 +703,41 @@ void destroy_batch_pipe(canny_hip_ctx::BatchPipe *w)
     }
     if (w->s_h2d) (void)hipStreamDestroy(w->s_h2d);
     if (w->s_d2h) (void)hipStreamDestroy(w->s_d2h);
-    canny_hip_ctx_destroy(w->sub);
+    if (w->owns_sub) canny_hip_ctx_destroy(w->sub);
     delete w;
 }
 
-int create_batch_pipe(canny_hip_ctx *ctx, canny_hip_ctx::BatchPipe **out)
+int create_batch_pipe(canny_hip_ctx *ctx, bool first, canny_hip_ctx::BatchPipe **out)
 {
     auto *w = new (std::nothrow) canny_hip_ctx::BatchPipe();
     if (!w) return CANNY_HIP_ERR_RUNTIME;
-    int st = canny_hip_ctx_create(&w->sub, ctx->device);
+    int st = CANNY_HIP_OK;
+    if (first) {
+        w->sub = ctx;
+    } else {
+        st = canny_hip_ctx_create(&w->sub, ctx->device);
+        w->owns_sub = st == CANNY_HIP_OK;
+    }
     hipError_t e = hipSuccess;
     if (!st) {
-        e = hipStreamCreateWithFlags(&w->s_h2d, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->s_d2h, hipStreamNonBlocking);
         for (auto &sl : w->slot)
             for (hipEvent_t *ev : {&sl.ev_h2d, &sl.ev_comp, &sl.ev_d2h})
                 if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
-        if (e != hipSuccess) st = fail(ctx, e, "batch pipeline streams/events");
+        if (e != hipSuccess) st = fail(ctx, e, "batch pipeline events");
     }
     if (st) {
         destroy_batch_pipe(w);
         return st;
     }
     *out = w;
+    return CANNY_HIP_OK;
+}
+
+// the copy streams of three-stream mode
+int ensure_copy_streams(canny_hip_ctx *ctx, canny_hip_ctx::BatchPipe &w)
+{
+    if (!w.s_h2d) HIP_TRY(ctx, hipStreamCreateWithFlags(&w.s_h2d, hipStreamNonBlocking));
+    if (!w.s_d2h) HIP_TRY(ctx, hipStreamCreateWithFlags(&w.s_d2h, hipStreamNonBlocking));
     return CANNY_HIP_OK;
 }
 
@@ -815,12 +855,13 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "sobel_nms_path") && value <= 2) ctx->sobel_nms_path = value;
     else if (!std::strcmp(name, "tune_sobel_seg") && value <= 4096) ctx->tune_sobel_seg = value;
     else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
-    else if (!std::strcmp(name, "smoothed_u8") && value <= 2) ctx->smoothed_u8 = value;
+    else if (!std::strcmp(name, "smoothed_u8") && value <= 1) ctx->smoothed_u8 = value;
+    else if (!std::strcmp(name, "hysteresis_tail") && value <= 1) ctx->hyst_tail = value;
     else if (!std::strcmp(name, "overlap_hysteresis") && value <= 1) ctx->overlap_hysteresis = value;
     else if (!std::strcmp(name, "tune_batch_workers") && value <= 16) ctx->batch_workers = value;
     else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) ctx->batch_chunk_mb = value;
     else if (!std::strcmp(name, "tune_batch_chunk_frames") && value <= 65535) ctx->batch_chunk_frames = value;
-    else if (!std::strcmp(name, "tune_batch_pipe_mode") && value <= 1) ctx->batch_pipe_mode = value;
+    else if (!std::strcmp(name, "tune_batch_pipe_mode") && value <= 2) ctx->batch_pipe_mode = value;
     else if (!std::strcmp(name, "stream_overlap") && value <= 1) {
         int rc = bind(ctx);
         if (rc || (rc = finish_pending(ctx))) return rc;
@@ -848,7 +889,23 @@ int canny_hip_synchronize(canny_hip_ctx *ctx)
 }
 
 const char *canny_hip_last_error(const canny_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
-int canny_hip_last_hysteresis_iterations(const canny_hip_ctx *ctx) { return ctx ? ctx->last_hyst_iters : 0; }
+int canny_hip_last_hysteresis_iterations(const canny_hip_ctx *cctx)
+{
+    canny_hip_ctx *ctx = const_cast<canny_hip_ctx *>(cctx);
+    if (!ctx) return 0;
+    if (ctx->hyst_iters_async && ctx->flags.p) {
+        // the tail path never reports to the host: fetch the last sweep that scheduled work (diagnostic, synchronises)
+        unsigned last = 0;
+        if (hipSetDevice(ctx->device) == hipSuccess &&
+            hipMemcpyAsync(&last, ctx->flags.p, sizeof last, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+            hipStreamSynchronize(ctx->stream) == hipSuccess)
+            ctx->last_hyst_iters = (int)last + 1;
+        else
+            (void)hipGetLastError();
+        ctx->hyst_iters_async = false;
+    }
+    return ctx->last_hyst_iters;
+}
 
 // ---- memory helpers -------------------------------------------------------------------------------
 int canny_hip_malloc(canny_hip_ctx *ctx, void **dev_ptr, size_t bytes)
@@ -1093,30 +1150,40 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
     };
     const bool in_pinned = is_pinned(imgs), out_pinned = is_pinned(edges);
     const bool all_pinned = in_pinned && out_pinned;
-    // chunk: 24 MB of input between pinned buffers, 16 MB when a pageable side has to be staged; never more than
-    // the 65535 frames a launch takes
+    // Defaults from the sweep on an MI355X box (tools/probe_batch_sweep.py, 128 x 4K and 256 x 1080p):
+    //   pinned buffers:   ONE three-stream pipeline, 24 MB chunks -- s16 maps 25.3 Gpix/s (D2H 50.6 GB/s: the link's
+    //                     rate with both directions busy), u8 maps 45.4 Gpix/s; a second pipeline only adds streams
+    //                     that fight for hardware queues (20.9 / 33.2);
+    //   pageable buffers: six single-stream pipelines, 8 MB chunks (the staging memcpys need the threads): 21.9 /
+    //                     32.4 Gpix/s.
+    // "tune_batch_pipe_mode": 1 = three streams, 2 = one in-order stream per pipeline, 0 = automatic.
+    const bool three_streams = ctx->batch_pipe_mode ? ctx->batch_pipe_mode == 1 : all_pinned;
     size_t chunk_frames = ctx->batch_chunk_frames
                               ? (size_t)ctx->batch_chunk_frames
-                              : ((size_t)(ctx->batch_chunk_mb ? ctx->batch_chunk_mb : (all_pinned ? 24 : 16)) << 20) / frame_px;
+                              : ((size_t)(ctx->batch_chunk_mb ? ctx->batch_chunk_mb : (all_pinned ? 24 : 8)) << 20) / frame_px;
+    // never more than the 65535 frames a launch takes
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)n_frames, 65535), chunk_frames));
     const int n_chunks = (n_frames + chunk - 1) / chunk;
-    const int n_workers = std::min(ctx->batch_workers ? ctx->batch_workers : (all_pinned ? 1 : 4), n_chunks);
+    const int n_workers = std::min(ctx->batch_workers ? ctx->batch_workers : (all_pinned ? 1 : 6), n_chunks);
     std::vector<int> status(n_workers, CANNY_HIP_OK);
     std::vector<std::string> errors(n_workers);
     while ((int)ctx->batch_pool.size() < n_workers) { // (sub-contexts are created here, on the caller's thread)
         Pipe *w = nullptr;
-        if ((rc = create_batch_pipe(ctx, &w))) return rc;
+        if ((rc = create_batch_pipe(ctx, ctx->batch_pool.empty(), &w))) return rc;
         ctx->batch_pool.push_back(w);
     }
+    if (three_streams)
+        for (int i = 0; i < n_workers; i++)
+            if ((rc = ensure_copy_streams(ctx, *ctx->batch_pool[i]))) return rc;
     const size_t out_elem = out_u8 ? 1 : sizeof(short);
 
     auto worker = [&](int wid) {
         Pipe &P = *ctx->batch_pool[wid];
         canny_hip_ctx *sub = P.sub;
         int &st = status[wid];
-        // A/B mode 1: uploads and downloads in order on the compute stream (overlap only between pipelines)
-        const hipStream_t s_h2d = ctx->batch_pipe_mode ? sub->stream : P.s_h2d;
-        const hipStream_t s_d2h = ctx->batch_pipe_mode ? sub->stream : P.s_d2h;
+        // single-stream mode: uploads and downloads in order on the compute stream (overlap only between pipelines)
+        const hipStream_t s_h2d = three_streams ? P.s_h2d : sub->stream;
+        const hipStream_t s_d2h = three_streams ? P.s_d2h : sub->stream;
         if (hipSetDevice(device) != hipSuccess) { // a new thread starts on device 0
             st = CANNY_HIP_ERR_RUNTIME;
             return;
@@ -1145,18 +1212,25 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             f0 = c * chunk;
             nf = std::min(chunk, n_frames - f0);
         };
-        // host -> d_in of chunk j.  The slot's previous user (chunk j - kSlots) has finished its kernels: the host
-        // blocked in dev_canny for it, so d_in and pin_in are free.
+        // host -> d_in of chunk j
         auto upload = [&](int j) -> hipError_t {
             Pipe::Slot &S = P.slot[j % Pipe::kSlots];
             int f0, nf;
             chunk_range(j, f0, nf);
             const unsigned char *src = imgs + (size_t)f0 * frame_px;
+            hipError_t err = hipSuccess;
+            if (j >= Pipe::kSlots) {
+                // the slot's previous user (chunk j - kSlots): its kernels must have read d_in (dev_canny no longer
+                // blocks the host), and its upload must have left pin_in
+                err = hipStreamWaitEvent(s_h2d, S.ev_comp, 0);
+                if (err == hipSuccess && !in_pinned) err = hipEventSynchronize(S.ev_h2d);
+                if (err != hipSuccess) return err;
+            }
             if (!in_pinned) {
                 std::memcpy(S.pin_in.p, src, frame_px * nf);
                 src = (const unsigned char *)S.pin_in.p;
             }
-            hipError_t err = hipMemcpyAsync(S.d_in.p, src, frame_px * nf, hipMemcpyHostToDevice, s_h2d);
+            err = hipMemcpyAsync(S.d_in.p, src, frame_px * nf, hipMemcpyHostToDevice, s_h2d);
             if (err == hipSuccess) err = hipEventRecord(S.ev_h2d, s_h2d);
             return err;
         };
@@ -1248,7 +1322,7 @@ struct MultiGpuState {
     std::mutex mu;
     std::vector<canny_hip_ctx *> shard_ctx; // index = shard
     std::vector<int> shard_dev;
-    int batch_workers = 0, batch_chunk_mb = 0, batch_chunk_frames = 0;
+    int batch_workers = 0, batch_chunk_mb = 0, batch_chunk_frames = 0, batch_pipe_mode = 0;
     int allow_device_reuse = 0; // shards beyond the device count wrap around (testing the sharder on a small box)
     int numa_affinity = 1;
 };
@@ -1334,6 +1408,7 @@ static int multi_gpu_impl(const unsigned char *imgs, int n_frames, float sigma, 
         ctx->batch_workers = g_mgpu.batch_workers;
         ctx->batch_chunk_mb = g_mgpu.batch_chunk_mb;
         ctx->batch_chunk_frames = g_mgpu.batch_chunk_frames;
+        ctx->batch_pipe_mode = g_mgpu.batch_pipe_mode;
         // run next to the GPU: this thread and the pipeline threads it starts inherit the mask.  The caller's own
         // thread (shard 0) gets its mask back afterwards.
         cpu_set_t local, saved;
@@ -1374,6 +1449,7 @@ int canny_hip_multi_gpu_set_option(const char *name, int value)
     if (!std::strcmp(name, "tune_batch_workers") && value <= 16) g_mgpu.batch_workers = value;
     else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) g_mgpu.batch_chunk_mb = value;
     else if (!std::strcmp(name, "tune_batch_chunk_frames") && value <= 65535) g_mgpu.batch_chunk_frames = value;
+    else if (!std::strcmp(name, "tune_batch_pipe_mode") && value <= 2) g_mgpu.batch_pipe_mode = value;
     else if (!std::strcmp(name, "allow_device_reuse") && value <= 1) g_mgpu.allow_device_reuse = value;
     else if (!std::strcmp(name, "numa_affinity") && value <= 1) g_mgpu.numa_affinity = value;
     else return CANNY_HIP_ERR_INVALID;
@@ -1487,13 +1563,13 @@ int canny_hip_dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int hei
 }
 
 int canny_hip_dev_gaussian_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int height, int width,
-                              int n_frames, unsigned char *d_result, int pk_convert)
+                              int n_frames, unsigned char *d_result)
 {
     int rc = bind(ctx);
     if (rc) return rc;
     if (!d_img || !d_result) return CANNY_HIP_ERR_INVALID;
     if ((rc = check_dims(height, width, n_frames))) return rc;
-    return dev_gaussian(ctx, d_img, sigma, height, width, n_frames, d_result, pk_convert ? 2 : 1);
+    return dev_gaussian(ctx, d_img, sigma, height, width, n_frames, d_result, 1);
 }
 
 int canny_hip_dev_sobel_nms_u8in(canny_hip_ctx *ctx, const unsigned char *d_smoothed, int height, int width,
@@ -1648,22 +1724,6 @@ int canny_hip_selftest_div(canny_hip_ctx *ctx, float divisor, unsigned long long
                            float *largest_mismatching_dividend)
 {
     return selftest_div_common(ctx, divisor, 0, 0.0f, mismatches, largest_mismatching_dividend);
-}
-
-int canny_hip_selftest_cvt_pk_u8(canny_hip_ctx *ctx, unsigned long long *mismatches, float *largest_mismatching_input)
-{
-    int rc = bind(ctx);
-    if (rc) return rc;
-    if (!mismatches || !largest_mismatching_input) return CANNY_HIP_ERR_INVALID;
-    HIP_TRY(ctx, ctx->io[0].ensure(2 * sizeof(unsigned long long)));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->io[0].p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(ctx, launch_selftest_cvt_pk_u8(0u, 0x43800000u /* 256.0f */, (unsigned long long *)ctx->io[0].p, ctx->stream));
-    unsigned long long res[2] = {0, 0};
-    if ((rc = d2h_sync(ctx, res, ctx->io[0].p, sizeof(res)))) return rc;
-    *mismatches = res[0];
-    unsigned bits = (unsigned)res[1];
-    std::memcpy(largest_mismatching_input, &bits, sizeof(float));
-    return CANNY_HIP_OK;
 }
 
 int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c)

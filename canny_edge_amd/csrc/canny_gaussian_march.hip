@@ -291,9 +291,10 @@ __device__ __forceinline__ void for_each_phase(F &&f, std::integer_sequence<int,
 // bound by VALU issue.  The lookups of one instruction hit 64 pixels 4 columns apart -- nearly equal values,
 // i.e. neighbouring or identical words: few bank conflicts on natural images.
 // OUT_U8: the smoothed plane is stored as bytes (src/utils.cpp:62: (short)(sum/count) always lies in [0,255]), one
-// dword store per lane and row instead of an 8-byte one; PK_U8 additionally converts and packs with
-// v_cvt_pk_u8_f32 (one instruction per pixel instead of v_cvt_i32_f32 + a share of the shifts/ors).
-template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV, bool USE_LUT, bool OUT_U8 = false, bool PK_U8 = false>
+// dword store per lane and row instead of an 8-byte one.  (v_cvt_pk_u8_f32 would convert and pack in one
+// instruction, but it rounds to nearest -- measured on the device: 41.9 M of the 1.13 G floats in [0,256] differ
+// from the truncating cast -- so the conversion stays v_cvt_i32_f32.)
+template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV, bool USE_LUT, bool OUT_U8 = false>
 __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussTaps &t, const float *lut,
                                                 float fma_c = 0.0f)
 {
@@ -306,7 +307,13 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 
     float T[C + 1]; // taps by distance from the centre
 #pragma unroll
-    for (int a = 0; a <= C; a++) T[a] = t.tap[C - a];
+    for (int a = 0; a <= C; a++) {
+        T[a] = t.tap[C - a];
+        // Keep the taps in VGPRs: a multiply with an SGPR operand is a slow-class instruction (~4.2 cycles of its
+        // pipe per wave against ~2.3 for v_mul_f32 v, v, v; tools/valu_issue_bench.hip), and every value is
+        // multiplied by C+1 of them.
+        asm volatile("" : "+v"(T[a]));
+    }
 
     // weights: full window (wave-uniform) and, at the column borders, this lane's four own weights
     float cnt_full = t.tap[0];
@@ -371,11 +378,23 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         if (!ROW_EDGE || (r >= 0 && r < H)) {
             float Q[4][C + 1];
             if (USE_LUT) {
+                // GAUSS_LUT_TAPS (experiment): only the products with the LUT_N outermost taps are looked up, the
+                // others multiplied -- the table trades VALU issue for LDS cycles, and either can be the bound
+#ifndef GAUSS_LUT_TAPS
+#define GAUSS_LUT_TAPS 99
+#endif
+                constexpr int LUT_N = GAUSS_LUT_TAPS < C + 1 ? GAUSS_LUT_TAPS : C + 1;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const float *row = lut + ((cur >> (8 * i)) & 0xffu);
+                    const unsigned px = (cur >> (8 * i)) & 0xffu;
+                    const float *row = lut + px;
 #pragma unroll
-                    for (int a = 0; a <= C; a++) Q[i][a] = row[a * 256];
+                    for (int a = C + 1 - LUT_N; a <= C; a++) Q[i][a] = row[a * 256];
+                    if (LUT_N < C + 1) {
+                        const float v = (float)px;
+#pragma unroll
+                        for (int a = 0; a < C + 1 - LUT_N; a++) Q[i][a] = __fmul_rn(v, T[a]);
+                    }
                 }
             } else {
                 const float v[4] = {(float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
@@ -389,44 +408,82 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
             // (same operands, same order, so the same bits) and arrive as one value whose wave shift folds into
             // the next add: every lane therefore computes pre[i] for its right neighbour.  Without this each of the
             // 4 outputs starts with a bare v_mov_b32_dpp and the two-lane hop costs another.
+            //
+            // Instruction ORDER matters as much as the count here: a DPP instruction between plain v_add_f32 costs
+            // the SIMD ~11 cycles, in a run of DPP instructions ~5, a plain add ~2.3 (tools/valu_issue_bench.hip:
+            // "52 plain then 12 DPP adds" 2.84 cycles per instruction against 3.93 with the same 12 spread singly).
+            // So the four output chains advance in lock step through phases -- all their DPP operations together,
+            // all their plain adds together -- with scheduling barriers between the phases.
             float pre[4];
+            // phase 1 (DPP): the terms the right neighbour's prefix takes from MY left neighbour
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                float s = 0.0f;
+                pre[i] = 0.0f;
+                bool open = false;
 #pragma unroll
                 for (int d = -C; d <= C; d++) {
                     const int e = i + d + 4, a = d < 0 ? -d : d; // the right neighbour's pixel i+d is my pixel e
-                    if (e >= 4) continue;                        // ... its own pixels and beyond: not mine to add
-                    const float term = e >= 0 ? Q[e][a] : lane_shr1(Q[e + 4][a]); // e < 0: from my own left
-                    s = (d == -C) ? term : __fadd_rn(s, term);
-                }
-                pre[i] = s;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float s = 0.0f;
-                bool open = false; // no term yet
-                if (i - C < 0) {
-                    s = lane_shr1(pre[i]);
+                    if (e >= 0) continue;
+                    const float term = lane_shr1(Q[e + 4][a]);
+                    pre[i] = open ? __fadd_rn(pre[i], term) : term;
                     open = true;
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 2 (plain): ... and from my own pixels
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+                for (int d = -C; d <= C; d++) {
+                    const int e = i + d + 4, a = d < 0 ? -d : d;
+                    if (e < 0 || e >= 4) continue;
+                    pre[i] = (d == -C) ? Q[e][a] : __fadd_rn(pre[i], Q[e][a]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 3 (DPP): each output starts from the prefix its left neighbour computed, folded into the add of
+            // its first own term
+            float sum[4];
+            bool started[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                started[i] = i - C < 0;
+                sum[i] = 0.0f;
+                if (started[i]) {
+                    const int d0 = -i, a0 = i;      // first own pixel: e = 0
+                    sum[i] = __fadd_rn(lane_shr1(pre[i]), Q[0][a0]);
+                    (void)d0;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 4 (plain): the rest of the own pixels
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
 #pragma unroll
                 for (int d = -C; d <= C; d++) {
                     const int e = i + d, a = d < 0 ? -d : d; // pixel e (relative to x0) at distance a
-                    if (e < 0) continue;                      // in pre[i]
-                    float term;
-                    if (e < 4) {
-                        term = Q[e][a];
-                    } else {
-                        const int hop = e / 4;
-                        term = lane_shl1(Q[e - 4 * hop][a]);
-                        if (hop == 2) term = lane_shl1(term);
-                    }
-                    s = open ? __fadd_rn(s, term) : term;
-                    open = true;
+                    if (e < 0 || e >= 4) continue;
+                    if (started[i] && e == 0) continue; // added in phase 3
+                    sum[i] = (!started[i] && d == -C) ? Q[e][a] : __fadd_rn(sum[i], Q[e][a]);
                 }
-                res[i] = FMA_DIV ? __fmaf_rn(s, fma_c, s) : div_by(s, cnt_h[i], inv_h[i]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 5 (DPP): the right neighbours' pixels, the four chains interleaved (distance by distance)
+#pragma unroll
+            for (int e = 4; e <= 3 + C; e++) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int d = e - i;
+                    if (d > C) continue;
+                    const int hop = e / 4;
+                    float term = lane_shl1(Q[e - 4 * hop][d]);
+                    if (hop == 2) term = lane_shl1(term);
+                    sum[i] = __fadd_rn(sum[i], term);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) res[i] = FMA_DIV ? __fmaf_rn(sum[i], fma_c, sum[i]) : div_by(sum[i], cnt_h[i], inv_h[i]);
         }
 
         // ---- column pass: row r is tap k of output row r + C - k --------------------------------------
@@ -468,17 +525,7 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         // float -> short truncates toward zero (src/utils.cpp:62)
         auto quot = [&](float a) { return FMA_DIV ? __fmaf_rn(a, fma_c, a) : div_by(a, cnt_v, inv_v); };
         uint2 pk;
-        if (OUT_U8 && PK_U8) {
-            // v_cvt_pk_u8_f32 truncates toward zero like the cast (checked for every float in [0,256] by
-            // canny_hip_selftest_cvt_pk_u8) and drops the result into byte k of the accumulating dword
-            uint32_t w = 0u;
-            asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(w) : "v"(quot(acc[DONE][0])));
-            asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(w) : "v"(quot(acc[DONE][1])));
-            asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(w) : "v"(quot(acc[DONE][2])));
-            asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(quot(acc[DONE][3])));
-            pk.x = w;
-            pk.y = 0u;
-        } else {
+        {
             const int o0 = (int)quot(acc[DONE][0]), o1 = (int)quot(acc[DONE][1]);
             const int o2 = (int)quot(acc[DONE][2]), o3 = (int)quot(acc[DONE][3]);
             if (OUT_U8) {
@@ -542,7 +589,7 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 
 // Live state per lane: 4(2C+1) open sums + 4(C+1) products + ~30; without an occupancy target the scheduler
 // interleaves several rows' products and doubles that.
-template <int C, bool USE_LUT, bool OUT_U8 = false, bool PK_U8 = false>
+template <int C, bool USE_LUT, bool OUT_U8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 5 ? 5 : 4)))
 void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, int H, int W, int n_strips,
                       int n_segs, int seg_rows, int total_waves, GaussTaps t, int use_fma_div, float fma_c)
@@ -580,16 +627,16 @@ void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, i
     const bool row_edge = (jb.ybeg - C < 0) || (jb.yend + C + K::RING >= H);
     if (col_edge) {
         if (row_edge)
-            gauss_sym_strip<C, true, true, false, USE_LUT, OUT_U8, PK_U8>(jb, t, lut);
+            gauss_sym_strip<C, true, true, false, USE_LUT, OUT_U8>(jb, t, lut);
         else
-            gauss_sym_strip<C, true, false, false, USE_LUT, OUT_U8, PK_U8>(jb, t, lut);
+            gauss_sym_strip<C, true, false, false, USE_LUT, OUT_U8>(jb, t, lut);
     } else {
         if (row_edge)
-            gauss_sym_strip<C, false, true, false, USE_LUT, OUT_U8, PK_U8>(jb, t, lut);
+            gauss_sym_strip<C, false, true, false, USE_LUT, OUT_U8>(jb, t, lut);
         else if (use_fma_div)
-            gauss_sym_strip<C, false, false, true, USE_LUT, OUT_U8, PK_U8>(jb, t, lut, fma_c);
+            gauss_sym_strip<C, false, false, true, USE_LUT, OUT_U8>(jb, t, lut, fma_c);
         else
-            gauss_sym_strip<C, false, false, false, USE_LUT, OUT_U8, PK_U8>(jb, t, lut);
+            gauss_sym_strip<C, false, false, false, USE_LUT, OUT_U8>(jb, t, lut);
     }
 }
 
@@ -708,8 +755,7 @@ hipError_t launch_selftest_div(float b, int use_fma, float c, unsigned first_bit
     return hipGetLastError();
 }
 
-// out_u8: 0 = s16 plane, 1 = u8 plane (v_cvt_i32_f32 + shifts/ors), 2 = u8 plane (v_cvt_pk_u8_f32); the u8 forms
-// exist for the symmetric-tap kernel with the product table only
+// out_u8: 0 = s16 plane, 1 = u8 plane; the u8 form exists for the symmetric-tap kernel with the product table only
 template <int C>
 static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int width, int n_frames,
                                  const GaussTaps &taps, hipStream_t stream, int out_u8)
@@ -754,12 +800,9 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
             std::memcpy(&fma_c, &e[1], sizeof(fma_c));
         }
     if (out_u8 && !(symmetric && march_variant == 0)) return hipErrorNotSupported;
-    if (out_u8 == 2)
-        hipLaunchKernelGGL((gauss_sym_kernel<C, true, true, true>), dim3(blocks), dim3(256), 0, stream, img, out, height,
+    if (out_u8)
+        hipLaunchKernelGGL((gauss_sym_kernel<C, true, true>), dim3(blocks), dim3(256), 0, stream, img, out, height,
                            width, n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
-    else if (out_u8)
-        hipLaunchKernelGGL((gauss_sym_kernel<C, true, true, false>), dim3(blocks), dim3(256), 0, stream, img, out,
-                           height, width, n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
     else if (symmetric && march_variant == 0)
         hipLaunchKernelGGL((gauss_sym_kernel<C, true>), dim3(blocks), dim3(256), 0, stream, img, out, height, width,
                            n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
@@ -805,50 +848,9 @@ bool gaussian_march_u8_supported(const GaussTaps &taps)
 }
 
 hipError_t launch_gaussian_march_u8(const uint8_t *img, uint8_t *out, int height, int width, int n_frames,
-                                    const GaussTaps &taps, hipStream_t stream, bool pk_convert)
+                                    const GaussTaps &taps, hipStream_t stream)
 {
-    return launch_march_any(img, out, height, width, n_frames, taps, stream, pk_convert ? 2 : 1);
-}
-
-// ---- v_cvt_pk_u8_f32 against the truncating cast, for every float in [first_bits, last_bits] ---------------
-__global__ __launch_bounds__(256) void selftest_cvt_pk_u8_kernel(unsigned first_bits, unsigned last_bits,
-                                                                  unsigned long long *mismatches)
-{
-    unsigned long long bad = 0, worst = 0;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long u = first_bits + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u <= last_bits;
-         u += stride) {
-        const float a = __uint_as_float((unsigned)u);
-        const int t = (int)a;                       // what the s16 kernels store (src/utils.cpp:62)
-        const unsigned want = t > 255 ? 255u : (unsigned)t; // a <= 256 here; 256.0 itself saturates
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t w = 0xa5a5a5a5u;
-            if (k == 0) asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(w) : "v"(a));
-            if (k == 1) asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(w) : "v"(a));
-            if (k == 2) asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(w) : "v"(a));
-            if (k == 3) asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(w) : "v"(a));
-            const uint32_t expect = (0xa5a5a5a5u & ~(0xffu << (8 * k))) | (want << (8 * k));
-            ok = ok && w == expect;
-        }
-        if (!ok) {
-            bad++;
-            worst = u;
-        }
-    }
-    if (bad) {
-        atomicAdd(mismatches, bad);
-        atomicMax(mismatches + 1, worst);
-    }
-}
-
-hipError_t launch_selftest_cvt_pk_u8(unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,
-                                     hipStream_t stream)
-{
-    hipLaunchKernelGGL(selftest_cvt_pk_u8_kernel, dim3(256 * 16), dim3(256), 0, stream, first_bits, last_bits,
-                       d_mismatches);
-    return hipGetLastError();
+    return launch_march_any(img, out, height, width, n_frames, taps, stream, 1);
 }
 
 } // namespace canny

@@ -52,13 +52,10 @@ hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, i
 
 // The same kernel storing the smoothed plane as BYTES ((short)(sum/count) lies in [0,255], src/utils.cpp:62):
 // half the store traffic, for the u8 form of the fused Sobel+NMS kernel.  Needs bit-symmetric taps and the default
-// march variant.  pk_convert: convert and pack with v_cvt_pk_u8_f32 instead of v_cvt_i32_f32 + shifts/ors.
+// march variant.
 bool gaussian_march_u8_supported(const GaussTaps &taps);
 hipError_t launch_gaussian_march_u8(const uint8_t *img, uint8_t *out, int height, int width, int n_frames,
-                                    const GaussTaps &taps, hipStream_t stream, bool pk_convert);
-// v_cvt_pk_u8_f32 vs the truncating cast (saturated at 255) over float bit patterns [first_bits, last_bits]
-hipError_t launch_selftest_cvt_pk_u8(unsigned first_bits, unsigned last_bits, unsigned long long *d_mismatches,
-                                     hipStream_t stream);
+                                    const GaussTaps &taps, hipStream_t stream);
 
 // (S, c) bit-pattern pairs for which the interior waves divide by the full-window weight S with one
 // fma(a, c, a); returns the number of entries.  gaussian_set_fma_div(false) disables the shortcut
@@ -117,9 +114,10 @@ hipError_t launch_sobel_nms_classify_march_u8in(const uint8_t *smoothed, int16_t
 // ---- Hysteresis (src/utils.cpp:322-427) -----------------------------------------------------
 hipError_t launch_hyst_classify(const int16_t *cand, uint64_t *strong, uint64_t *conn, const HystGeom &g, int min_val,
                                 int max_val, unsigned *domain_flag, hipStream_t stream);
-// One propagation sweep (`iter` = 0,1,2,...).  sched holds hyst_sched_words(g) words (tile stamps, two
-// work queues, three queue counters) and, like the single word last_change, must be zero before sweep 0.
-inline size_t hyst_sched_words(const HystGeom &g) { return 3 * (size_t)g.tiles() + 4; }
+// One propagation sweep (`iter` = 0,1,2,...).  sched holds hyst_sched_words(g) words (tile stamps, two batch-wide
+// work queues with three counters, two per-frame work queues with four counter words per frame) and, like the
+// single word last_change, must be zero before sweep 0.
+inline size_t hyst_sched_words(const HystGeom &g) { return 5 * (size_t)g.tiles() + 4 + 4 * (size_t)g.n_frames; }
 // First launch of a hysteresis call: zeroes sched (hyst_sched_words(g) words) and flags[0..1] (last_change,
 // domain) and, if zero_pad, the plane bits outside the image (tile padding; needed when the planes are filled
 // by launch_sobel_nms_classify_march, which writes in-image bytes only; requires width % 8 == 0).
@@ -129,9 +127,17 @@ hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom 
                                unsigned *flags, hipStream_t stream, int n_lanes = 1);
 // edges != nullptr: an edge map that already holds the initially strong pixels; each sweep writes edge_value
 // into the pixels it promotes, so the map is final when propagation has converged (no finalize pass).
+// to_frame_queues: the tiles this sweep schedules go into their frame's queue (the sweep before launch_hyst_tail).
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
                                  int iter, const HystGeom &g, hipStream_t stream, int16_t *edges = nullptr,
-                                 int edge_value = 0);
+                                 int edge_value = 0, bool to_frame_queues = false);
+// Every sweep from first_iter on, to convergence, in ONE launch: one workgroup per frame walks that frame's queue
+// with a workgroup barrier between sweeps (frames are independent; see hyst_tail_kernel).  The sweep first_iter - 1
+// must have been launched with to_frame_queues = true.  No host round trip: the propagation is complete when the
+// stream has passed this kernel.
+hipError_t launch_hyst_tail(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
+                            int first_iter, const HystGeom &g, hipStream_t stream, int16_t *edges = nullptr,
+                            int edge_value = 0);
 // s16 edge map (0 / 255) -> u8, n pixels.
 hipError_t launch_edges_to_u8(const int16_t *edges, uint8_t *out, size_t n, hipStream_t stream);
 // Copies flags[0..1] (last_change, domain) to host_flags_dev[0..1] and then stores seq to host_flags_dev[2]

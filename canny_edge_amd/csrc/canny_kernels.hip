@@ -433,8 +433,11 @@ __device__ __forceinline__ uint64_t fill_runs(uint64_t p, uint64_t g)
 //   stamp[tiles]    sweep at which a tile was last queued (dedupes pushes within a sweep)
 //   queue[2][tiles] tiles to run in sweep k are queue[k & 1][0 .. count[k % 3])
 //   count[3]        sweep k reads count[k%3], appends to count[(k+1)%3] and clears count[(k+2)%3]
+//   fq0/fq1[tiles]  the same two queues PER FRAME (frame f owns [f * tiles_per_frame, (f+1) * tiles_per_frame)),
+//   fcount[4 * frames] ... and their counters (3 used per frame): what hyst_tail_kernel walks, one workgroup per frame
 struct HystSched {
     unsigned *stamp, *queue0, *queue1, *count;
+    unsigned *fq0, *fq1, *fcount;
 };
 constexpr int kSweep0Tiles = 2; // tiles per wave in sweep 0
 __device__ __forceinline__ HystSched make_sched(unsigned *words, int tiles)
@@ -444,6 +447,9 @@ __device__ __forceinline__ HystSched make_sched(unsigned *words, int tiles)
     s.queue0 = words + tiles;
     s.queue1 = words + 2 * (size_t)tiles;
     s.count = words + 3 * (size_t)tiles;
+    s.fq0 = words + 3 * (size_t)tiles + 4;
+    s.fq1 = words + 4 * (size_t)tiles + 4;
+    s.fcount = words + 5 * (size_t)tiles + 4;
     return s;
 }
 
@@ -481,10 +487,11 @@ __device__ __forceinline__ TileIn load_tile(int t, int lane, const uint64_t *__r
 
 // c = this lane's word of the tile's connectable plane (the caller has checked that the tile has any), in = the
 // tile as load_tile() returned it.
+// to_frame: neighbours are queued in their FRAME's queue (for hyst_tail_kernel) instead of the batch-wide one.
 __device__ __forceinline__ void process_tile(int t, int lane, uint64_t *__restrict__ strong, const HystSched &sch,
                                              unsigned *__restrict__ last_change, int iter, const HystGeom &g,
                                              int16_t *__restrict__ edges, int edge_value, uint64_t c,
-                                             const TileIn &in)
+                                             const TileIn &in, bool to_frame = false)
 {
     const int tpf = g.tiles_x * g.tiles_y;
     const int tt = t % tpf;
@@ -542,6 +549,11 @@ __device__ __forceinline__ void process_tile(int t, int lane, uint64_t *__restri
             const unsigned nxt = (unsigned)iter + 1u;
             unsigned *q = (nxt & 1u) ? sch.queue1 : sch.queue0;
             unsigned *cnt = sch.count + nxt % 3u;
+            if (to_frame) {
+                const int f = t / tpf;
+                q = ((nxt & 1u) ? sch.fq1 : sch.fq0) + (size_t)f * tpf;
+                cnt = sch.fcount + 4 * (size_t)f + nxt % 3u;
+            }
             bool marked = false;
             auto push = [&](int nb) {
                 if (atomicExch(&sch.stamp[nb], nxt) != nxt) q[atomicAdd(cnt, 1u)] = (unsigned)nb;
@@ -563,14 +575,15 @@ __device__ __forceinline__ void process_tile(int t, int lane, uint64_t *__restri
 __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__restrict__ strong,
                                                const uint64_t *__restrict__ conn, const HystSched &sch,
                                                unsigned *__restrict__ last_change, int iter, const HystGeom &g,
-                                               int16_t *__restrict__ edges, int edge_value, uint64_t c)
+                                               int16_t *__restrict__ edges, int edge_value, uint64_t c,
+                                               bool to_frame = false)
 {
     // c = this lane's word of the tile's connectable plane, loaded by the caller.  Only connectable pixels can
     // ever be added, so a tile without a single one (flat regions: most tiles of a natural frame) cannot
     // change: leave before the strong plane and the nine halo loads are touched.
     if (!__any(c != 0)) return;
     const TileIn in = load_tile(t, lane, strong, g);
-    process_tile(t, lane, strong, sch, last_change, iter, g, edges, edge_value, c, in);
+    process_tile(t, lane, strong, sch, last_change, iter, g, edges, edge_value, c, in, to_frame);
 }
 
 // Sweep 0 visits every tile (grid = tiles / (4 kSweep0Tiles) workgroups); later sweeps are launched with a small fixed
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
                                                              const uint64_t *__restrict__ conn,
                                                              unsigned *__restrict__ sched_words,
                                                              unsigned *__restrict__ last_change, int iter, HystGeom g,
-                                                             int16_t *__restrict__ edges, int edge_value)
+                                                             int16_t *__restrict__ edges, int edge_value, int to_frame)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -600,7 +613,8 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
                 c[k] = (t0 + k < tiles) ? conn[(size_t)(t0 + k) * kTile + lane] : 0ull;
 #pragma unroll
             for (int k = 0; k < kSweep0Tiles; k++)
-                propagate_tile(t0 + k, lane, strong, conn, sch, last_change, iter, g, edges, edge_value, c[k]);
+                propagate_tile(t0 + k, lane, strong, conn, sch, last_change, iter, g, edges, edge_value, c[k],
+                               to_frame != 0);
         }
         return;
     }
@@ -609,7 +623,47 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
     for (unsigned i = (unsigned)wave; i < n; i += (unsigned)n_waves) {
         const int t = (int)q[i];
         propagate_tile(t, lane, strong, conn, sch, last_change, iter, g, edges, edge_value,
-                       conn[(size_t)t * kTile + lane]);
+                       conn[(size_t)t * kTile + lane], to_frame != 0);
+    }
+}
+
+// The tail of a propagation: ONE workgroup per frame runs every remaining sweep of its frame, until the frame's
+// queue stays empty.  Frames never interact (the reference processes one frame per call, src/main.cpp:120-137), so a
+// frame's sweeps only have to be ordered among the waves that work on that frame -- a workgroup barrier -- and no
+// grid-wide barrier, no cross-workgroup visibility protocol and no host round trip is needed: after the two
+// batch-wide sweeps that do the bulk of the work (sweep 1 queues into the per-frame queues), this kernel replaces
+// the 6+ nearly empty launches and the host's convergence poll of the multi-launch scheme.
+// Termination: strong bits only ever get set, a tile is queued only when a neighbour's facing border changed, so
+// every frame's queue runs dry after finitely many sweeps; the loop has no other exit and needs none.
+// Visibility: all waves of a workgroup run on one CU and share its L1; __syncthreads() orders their stores and
+// atomics (workgroup scope) before the next sweep's loads.
+__global__ __launch_bounds__(1024) void hyst_tail_kernel(uint64_t *__restrict__ strong, const uint64_t *__restrict__ conn,
+                                                         unsigned *__restrict__ sched_words,
+                                                         unsigned *__restrict__ last_change, int first_iter, HystGeom g,
+                                                         int16_t *__restrict__ edges, int edge_value)
+{
+    __shared__ unsigned s_n;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
+    const int f = blockIdx.x;
+    const int tpf = g.tiles_x * g.tiles_y;
+    const HystSched sch = make_sched(sched_words, g.tiles());
+    unsigned *const fcount = sch.fcount + 4 * (size_t)f;
+    for (int iter = first_iter;; iter++) {
+        if (threadIdx.x == 0) {
+            s_n = __hip_atomic_load(fcount + iter % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fcount[(iter + 2) % 3] = 0; // the slot sweep iter+1 will append to
+        }
+        __syncthreads();
+        const unsigned n = s_n;
+        if (n == 0) break; // uniform: every thread of the workgroup read the same s_n
+        const unsigned *q = ((iter & 1) ? sch.fq1 : sch.fq0) + (size_t)f * tpf;
+        for (unsigned i = (unsigned)wave; i < n; i += (unsigned)n_waves) {
+            const int t = (int)__hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            propagate_tile(t, lane, strong, conn, sch, last_change, iter, g, edges, edge_value,
+                           conn[(size_t)t * kTile + lane], /*to_frame=*/true);
+        }
+        __syncthreads(); // this sweep's stores and queue pushes are complete (and s_n may be rewritten)
     }
 }
 
@@ -870,8 +924,8 @@ hipError_t launch_hyst_prepare(uint64_t *strong, uint64_t *conn, const HystGeom 
     const bool pad = zero_pad && (g.height % kTile != 0 || g.width % kTile != 0);
     const long long pad_waves = pad ? (long long)(g.tiles_x + g.tiles_y) * g.n_frames : 0;
     // n_lanes independent propagations over disjoint frame ranges: their scheduling words lie back to back
-    // (3 words per tile + 4 per lane) and so do their flag pairs
-    const size_t n_sched = 3 * (size_t)g.tiles() + 4 * (size_t)n_lanes;
+    // (hyst_sched_words() of each range: 5 words per tile + 4 per frame + 4) and so do their flag pairs
+    const size_t n_sched = 5 * (size_t)g.tiles() + 4 * (size_t)n_lanes + 4 * (size_t)g.n_frames;
     const long long waves = pad_waves + (long long)((n_sched + 255) / 256);
     if (pad_waves > 0x3fffffffLL || n_sched > 0xffffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(hyst_prepare_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, strong, conn, g,
@@ -926,8 +980,21 @@ hipError_t launch_hyst_publish(const unsigned *flags, unsigned *host_flags_dev, 
     return hipGetLastError();
 }
 
+hipError_t launch_hyst_tail(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
+                            int first_iter, const HystGeom &g, hipStream_t stream, int16_t *edges, int edge_value)
+{
+    if (g.n_frames < 1 || first_iter < 1) return hipErrorInvalidValue;
+    // one workgroup per frame; 16 waves while a frame has enough tiles to keep them busy
+    const int tpf = g.tiles_x * g.tiles_y;
+    const unsigned threads = tpf >= 256 ? 1024u : (tpf >= 64 ? 512u : 256u);
+    hipLaunchKernelGGL(hyst_tail_kernel, dim3((unsigned)g.n_frames), dim3(threads), 0, stream, strong, conn, sched,
+                       last_change, first_iter, g, edges, edge_value);
+    return hipGetLastError();
+}
+
 hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigned *stamp, unsigned *last_change,
-                                 int iter, const HystGeom &g, hipStream_t stream, int16_t *edges, int edge_value)
+                                 int iter, const HystGeom &g, hipStream_t stream, int16_t *edges, int edge_value,
+                                 bool to_frame_queues)
 {
     unsigned blocks = (unsigned)((g.tiles() + 4 * kSweep0Tiles - 1) / (4 * kSweep0Tiles)); // sweep 0: all tiles
     if (iter > 0) { // queue walkers: at most 16 waves per CU, and no more than a wave per 4 tiles (a single frame's
@@ -936,7 +1003,7 @@ hipError_t launch_hyst_propagate(uint64_t *strong, const uint64_t *conn, unsigne
         blocks = want < 8u ? 8u : (want > 1024u ? 1024u : want);
     }
     hipLaunchKernelGGL(hyst_propagate_kernel, dim3(blocks), dim3(256), 0, stream, strong, conn, stamp, last_change,
-                       iter, g, edges, edge_value);
+                       iter, g, edges, edge_value, to_frame_queues ? 1 : 0);
     return hipGetLastError();
 }
 // Row-major finalize: a wave writes 512 consecutive pixels of ONE row (1 KB contiguous, four rows per

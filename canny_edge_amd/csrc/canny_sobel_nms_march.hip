@@ -14,7 +14,8 @@
 //       n = gx^2+gy^2,  mag = trunc(sqrt(n+0.5)),  P = gx*gy,  q = (gx^2-gy^2)/2
 //       bin 0 iff |P| <= q, bin 90 iff |P| < -q, else 45 (P > 0) / 135   [same rule as angle_bin_d8]
 //   NMS one row later, when the magnitudes of the row below exist: strict max against the two
-//       neighbours of the bin; neighbours outside the image carry magnitude -1 (= "skip").
+//       neighbours of the bin; neighbours outside the image carry the lowest magnitude there is (0, or the
+//       threshold floor of the PLANES kernel), which never changes an output (= "skip", see `skip` below).
 // Three rows of d/t, of magnitudes and of bin discriminants rotate through registers; the row loop is
 // unrolled by 3 so that every rotation is a compile-time renaming and the three prefetched rows never
 // have to be copied while their loads are in flight.
@@ -23,7 +24,7 @@
 //   gx: column clamp  -> zero-filled neighbours plus a +-s fix-up at columns 0 and W-1; rows dropped
 //       (virtual rows are zero, which is exactly "dropped");
 //   gy: columns dropped (zero fill), row clamp -> t[-1]:=t[0], t[H]:=t[H-1];
-//   NMS: out-of-image neighbours skipped -> magnitude -1.
+//   NMS: out-of-image neighbours skipped -> lowest magnitude.
 // Column borders exist only in the first and last strip: those waves run the COL_EDGE=true
 // instantiation, every other wave runs code with no lane-varying border logic at all.  Row borders are
 // wave-uniform (the wave index goes through readfirstlane) and sit behind scalar branches.
@@ -133,17 +134,17 @@ struct StripJob {
 // the classify pass (2 B/px of loads) and the finalize pass (2 B/px of stores in an HBM-bound kernel) both
 // disappear from the pipeline.  Stores are what this kernel's row loop stalls on ("store latency"),
 // so the plane bytes do not go out row by row: see LDS_PLANES below.
-// max(a, b, c) with a wave-uniform c in one instruction (the compiler turns max(max(a, b), c) into
-// max(max(a, c), max(b, c)) with the clamped magnitudes shared between pixels: one more v_max per pixel)
-__device__ __forceinline__ int max3_uniform(int a, int b, int c)
+// max of two magnitudes as ONE v_max_u16.  Magnitudes are 0..1442, so the unsigned 16-bit maximum of the low
+// halves is the maximum, and the instruction zeroes the upper half of its result (gfx9 VOP2 16-bit rule).  It is
+// here for its issue cost: v_max_u16 with VGPR operands issues every ~2.3 cycles per SIMD like v_add_f32, while
+// v_max_i32 / v_max3_i32 take ~4.2 (tools/valu_issue_bench.hip, DESIGN.md "instruction classes").
+__device__ __forceinline__ int max_u16(int a, int b)
 {
     int r;
-    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    asm("v_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
-// IN_U8 (NP = 4 only): the smoothed plane arrives as bytes -- one 8-byte load per lane and row instead of a 16-byte
-// one; four v_perm_b32 spread the eight bytes into the four s16 pairs the rest of the kernel works on.
 template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP, bool LDS_PLANES, bool IN_U8 = false>
 __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_mem, const uint4 *edge_lut = nullptr)
 {
@@ -205,6 +206,16 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
         }
     };
 
+    // Magnitude of a pixel NMS must skip (outside the image), and the floor every stored magnitude is raised to:
+    //   plain kernel:  0.  The reference skips the comparison; comparing against 0 instead gives the same OUTPUT,
+    //                  because the only case that differs (mc == 0 "survives" a skipped neighbour) writes 0 either way.
+    //   PLANES kernel: min_val - 1 (>= 0).  A pixel is connectable iff mc > max(neighbours, min_val - 1); with every
+    //                  magnitude m replaced by m' = max(m, min_val - 1) that is mc' > max(neighbours') -- for
+    //                  mc <= min_val - 1 both sides are false, otherwise mc' = mc and the floor under the neighbours
+    //                  is the third operand the old v_max3_i32 carried.  One v_max_u16 per pixel instead of a wider
+    //                  maximum in each of the four neighbour pairs.
+    int skip = PLANES ? jb.lo1 : 0; // in a VGPR on purpose: an SGPR operand makes the maximum a slow-class instruction
+    asm volatile("" : "+v"(skip));
     // rotating state (all indices are compile-time after unrolling by 3)
     uint32_t d[3][NP], t[3][NP]; // horizontal difference / smooth of rows r, r-1, r-2
     int M[3][PX + 2];            // magnitudes of rows r-1, r-2, r-3; [0] and [PX+1] are the neighbours' edge pixels
@@ -214,7 +225,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
 #pragma unroll
         for (int i = 0; i < NP; i++) d[a][i] = t[a][i] = 0u;
 #pragma unroll
-        for (int e = 0; e < PX + 2; e++) M[a][e] = -1;
+        for (int e = 0; e < PX + 2; e++) M[a][e] = skip;
 #pragma unroll
         for (int e = 0; e < PX; e++) cP[a][e] = cQ[a][e] = 0.0f;
     }
@@ -328,7 +339,8 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                     //   Ah = gx^2 + 1/2,  nh = gx^2 + gy^2 + 1/2,  P = gx*gy,  Q = Ah - nh/2 = (gx^2-gy^2)/2 + 1/4
                     const float Ah = __fmaf_rn(fx, fx, 0.5f);
                     const float nh = __fmaf_rn(fy, fy, Ah);
-                    M[m2][e + 1] = (int)__builtin_amdgcn_sqrtf(nh); // floor(sqrt(n)), see magnitude_d8
+                    const int mag = (int)__builtin_amdgcn_sqrtf(nh); // floor(sqrt(n)), see magnitude_d8
+                    M[m2][e + 1] = PLANES ? max_u16(mag, skip) : mag;
                     cP[m2][e] = __fmul_rn(fx, fy);
                     cQ[m2][e] = __fmaf_rn(nh, -0.5f, Ah);
                 }
@@ -336,14 +348,14 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
             if (COL_EDGE) { // columns outside the image never win a comparison
 #pragma unroll
                 for (int e = 0; e < PX; e++)
-                    if (oob & (1u << e)) M[m2][e + 1] = -1;
+                    if (oob & (1u << e)) M[m2][e + 1] = skip;
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < PX; e++) M[m2][e + 1] = -1; // rows outside the image are skipped by NMS
+            for (int e = 0; e < PX; e++) M[m2][e + 1] = skip; // rows outside the image are skipped by NMS
         }
-        // edge pixels of the neighbouring lanes (lanes 0 and 63 get 0 here; they are halo lanes whose
-        // own NMS results are never stored, and their neighbours only read M[PX] / M[1] from them)
+        // edge pixels of the neighbouring lanes (lanes 0 and 63 get 0 here -- below the PLANES floor, harmless: they
+        // are halo lanes whose own NMS results are never stored, and their neighbours only read M[PX] / M[1] from them)
         M[m2][0] = (int)from_left((uint32_t)M[m2][PX]);
         M[m2][PX + 1] = (int)from_right((uint32_t)M[m2][1]);
 
@@ -357,8 +369,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                 const int e = PLANES ? PX - 1 - ee : ee; // planes: last pixel first, so that pixel e ends up in bit e
                 const int c = e + 1;
                 const int mc = M[m1][c];
-                // PLANES: min_val - 1 rides along as the third operand of a v_max3_i32 -- no extra instruction
-                auto nmax = [&](int a, int b) { return PLANES ? max3_uniform(a, b, jb.lo1) : max(a, b); };
+                auto nmax = [&](int a, int b) { return max_u16(a, b); };
                 const int n0 = nmax(M[m1][c - 1], M[m1][c + 1]);
                 const int n90 = nmax(M[m0][c], M[m2][c]);
                 const int n45 = nmax(M[m0][c + 1], M[m2][c - 1]);  // up-right, down-left

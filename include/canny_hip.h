@@ -98,18 +98,28 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "gaussian_fma_div": 1 (default) / 0 -- single-fma division by the full-window weight (process-wide)
  *   "fuse_classify": 1 (default) / 0 -- canny(): the Sobel+NMS kernel writes the hysteresis bit-planes itself
  *                    (used when width % 8 == 0 and min_val >= 1; otherwise the separate kernels run)
- *   "smoothed_u8": 0 (default) / 1 / 2 -- canny(): the smoothed plane between the Gaussian and the fused Sobel+NMS
+ *   "smoothed_u8": 0 (default) / 1 -- canny(): the smoothed plane between the Gaussian and the fused Sobel+NMS
  *                    kernel is stored as bytes instead of shorts ((short)(sum/count) lies in [0,255],
- *                    src/utils.cpp:62): 5.25 instead of 7.25 algorithmic bytes per pixel through HBM; 2 converts with
- *                    v_cvt_pk_u8_f32.  Used when the fused path and the marching Gaussian apply, else ignored.
+ *                    src/utils.cpp:62): 5.25 instead of 7.25 algorithmic bytes per pixel through HBM.
+ *                    Used when the fused path and the marching Gaussian apply, else ignored.
  *                    Same results bit for bit
+ *   "hysteresis_tail": 1 (default) / 0 -- canny(): after two batch-wide propagation sweeps ONE launch with a workgroup
+ *                    per frame runs the remaining sweeps to convergence (frames are independent, so a workgroup
+ *                    barrier between a frame's sweeps is all the ordering needed).  The call then queues five
+ *                    kernels and returns without waiting: no per-sweep launches, no host round trip.  Used for
+ *                    frames of up to 4096 tiles of 64x64 (a 4K frame has 2040); 0 = the multi-launch scheme whose
+ *                    host polls for convergence
  *   "overlap_hysteresis": 0 (default) / 1 -- canny() on 16 or more frames: the propagation sweeps of the first half
  *                    of the batch run on a second stream beside the Sobel+NMS kernel of the second half
  *                    (measured 1.5 % slower on 128 x 4K, kept for A/B)
- *   "tune_batch_workers", "tune_batch_chunk_mb", "tune_batch_chunk_frames": canny_hip_canny_batch's pipelines (a host
- *                    thread with an upload, a compute and a download stream each) and the chunk size in megabytes of
- *                    input or in frames (frames win); 0 (default) = automatic: one pipeline x 24 MB chunks between
- *                    pinned buffers, four x 16 MB when a pageable buffer has to be staged
+ *   "tune_batch_workers", "tune_batch_chunk_mb", "tune_batch_chunk_frames", "tune_batch_pipe_mode":
+ *                    canny_hip_canny_batch's pipelines (host threads), the chunk size in megabytes of input or in
+ *                    frames (frames win) and the stream structure of a pipeline (1 = upload, compute and download
+ *                    stream chained by events, 2 = one in-order stream); 0 (default) = automatic: one three-stream
+ *                    pipeline x 24 MB chunks between pinned buffers, six single-stream pipelines x 8 MB when a
+ *                    pageable buffer has to be staged.  HIP multiplexes a process's streams onto 4 hardware queues by
+ *                    default (GPU_MAX_HW_QUEUES): a host application with many streams of its own should raise that
+ *                    limit, or the three streams of the pipeline end up sharing a queue and serialise
  *   "stream_overlap": 0 (default) / 1 -- canny_hip_dev_canny_stream: the sweeps left in flight run on a second,
  *                    high-priority stream beside the next call's Gaussian instead of in order before it
  *                    (no gain on 128 x 4K batches, kept for A/B)
@@ -184,7 +194,8 @@ int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sig
                               int height, int width, short *edges, int n_devices);
 int canny_hip_canny_multi_gpu_u8(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
                                  int height, int width, unsigned char *edges, int n_devices);
-/* Process-wide options of the sharder: "tune_batch_workers" / "tune_batch_chunk_mb" / "tune_batch_chunk_frames"
+/* Process-wide options of the sharder: "tune_batch_workers" / "tune_batch_chunk_mb" / "tune_batch_chunk_frames" /
+ * "tune_batch_pipe_mode"
  * (applied to every shard's pipeline), "numa_affinity" 1 (default) / 0, "allow_device_reuse" 0 (default) / 1:
  * n_devices may exceed the device count, shard s then runs on device s % count (exercises the sharder with N > 1
  * on a one-GPU box; no use in production). */
@@ -211,10 +222,10 @@ int canny_hip_dev_nms(canny_hip_ctx *ctx, const short *d_magnitude, const short 
 int canny_hip_dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int height, int width, int n_frames,
                             short *d_nms);
 /* The two kernels of canny()'s "smoothed_u8" path on their own (tests, A/B): the Gaussian storing bytes
- * (pk_convert != 0: v_cvt_pk_u8_f32), and the fused Sobel+NMS reading them (3 algorithmic bytes per pixel).
+ * and the fused Sobel+NMS reading them (3 algorithmic bytes per pixel).
  * CANNY_HIP_ERR_UNSUPPORTED where the marching kernels do not apply (window > 17, asymmetric taps, A/B variants). */
 int canny_hip_dev_gaussian_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int height, int width,
-                              int n_frames, unsigned char *d_result, int pk_convert);
+                              int n_frames, unsigned char *d_result);
 int canny_hip_dev_sobel_nms_u8in(canny_hip_ctx *ctx, const unsigned char *d_smoothed, int height, int width,
                                  int n_frames, short *d_nms);
 /* In place.  Blocks the host until propagation has converged (it polls a device flag). */
@@ -263,9 +274,6 @@ int canny_hip_selftest_div_fma(canny_hip_ctx *ctx, float divisor, float c, unsig
                                float *largest_mismatching_dividend);
 /* Entry `index` of the built-in (divisor, c) table the kernels use; CANNY_HIP_ERR_INVALID past the end. */
 int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c);
-/* v_cvt_pk_u8_f32 (the "smoothed_u8" = 2 conversion) against the truncating cast saturated at 255, for every float
- * in [0, 256], all four byte positions. */
-int canny_hip_selftest_cvt_pk_u8(canny_hip_ctx *ctx, unsigned long long *mismatches, float *largest_mismatching_input);
 /* Host-only: number of CPUs in a sysfs-style list ("0-3,8,10-11" -> 7; 0 if malformed) -- the parser behind the
  * sharder's NUMA binding. */
 int canny_hip_selftest_cpulist_count(const char *text);

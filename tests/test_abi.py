@@ -115,8 +115,8 @@ def test_cpulist_parser_behind_the_numa_binding(text, count):
 
 
 def test_multi_gpu_options_are_validated_without_a_gpu():
-    for name in ("tune_batch_workers", "tune_batch_chunk_mb", "tune_batch_chunk_frames", "allow_device_reuse",
-                 "numa_affinity"):
+    for name in ("tune_batch_workers", "tune_batch_chunk_mb", "tune_batch_chunk_frames", "tune_batch_pipe_mode",
+                 "allow_device_reuse", "numa_affinity"):
         capi.multi_gpu_set_option(name, 1)
         capi.multi_gpu_set_option(name, 0)
     capi.multi_gpu_set_option("numa_affinity", 1)

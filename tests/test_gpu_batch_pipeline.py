@@ -78,13 +78,15 @@ def _run(ctx, frames, u8, mem, out_dtype):
 @pytest.mark.parametrize("u8", [False, True], ids=["s16", "u8"])
 @pytest.mark.parametrize("mem", ["pageable", "pinned", "pinned_in", "pinned_out"])
 @pytest.mark.parametrize("workers", [1, 2, 3, 4])
-def test_batch_across_chunk_and_pipeline_boundaries(hip, batch_270, batch_odd, workers, mem, u8):
+@pytest.mark.parametrize("pipe_mode", [0, 1, 2], ids=["auto", "three_streams", "one_stream"])
+def test_batch_across_chunk_and_pipeline_boundaries(hip, batch_270, batch_odd, pipe_mode, workers, mem, u8):
     """43 x 270x480 in 1 MB chunks = 8 frames per chunk, 6 chunks, the last one 3 frames; then 41 x 37x53 in
     chunks of 6 frames (7 chunks, last one 5) on the SAME context, then the first shape again: the staging
     buffers and pipelines cached in the context are reused across calls with different shapes."""
     dtype = np.uint8 if u8 else np.int16
     with hip.Context(0) as ctx:
         ctx.set_option("tune_batch_workers", workers)
+        ctx.set_option("tune_batch_pipe_mode", pipe_mode)
         for frames, want, chunk_opt in ((batch_270[0], batch_270[1], ("tune_batch_chunk_mb", 1)),
                                         (batch_odd[0], batch_odd[1], ("tune_batch_chunk_frames", 6)),
                                         (batch_270[0][:19], batch_270[1][:19], ("tune_batch_chunk_frames", 4))):
@@ -93,7 +95,7 @@ def test_batch_across_chunk_and_pipeline_boundaries(hip, batch_270, batch_odd, w
             ctx.set_option(*chunk_opt)
             got = _run(ctx, frames, u8, mem, dtype)
             assert got.dtype == dtype
-            _assert_frames_equal(got.astype(np.int16), want, f"workers={workers} {mem} u8={u8} {chunk_opt}")
+            _assert_frames_equal(got.astype(np.int16), want, f"mode={pipe_mode} workers={workers} {mem} u8={u8} {chunk_opt}")
 
 
 def test_batch_more_pipelines_than_chunks_and_single_frame_chunks(hip, batch_270):

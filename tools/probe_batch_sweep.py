@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""canny_hip_canny_batch / _u8 host->host sweep: pipeline mode (three streams vs one in-order stream per pipeline)
+"""canny_hip_canny_batch / _u8 host->host sweep: pipeline mode (1 three streams, 2 one in-order stream per pipeline)
 x pipelines x chunk size, pinned and pageable buffers, on 128 x 4K (sigma 1.4) and 256 x 1080p (sigma 1.0).
 Prints one line per configuration and the best per (shape, dtype, memory)."""
 import os
@@ -24,7 +24,7 @@ for (H, W, N, sigma) in ((2160, 3840, 128, 1.4), (1080, 1920, 256, 1.0)):
         for u8 in (False, True):
             dt = np.uint8 if u8 else np.int16
             dst = ctx.pinned_array((N, H, W), dt) if mem == "pinned" else np.empty((N, H, W), dt)
-            for mode in (0, 1):
+            for mode in (1, 2):
                 for workers in ((1, 2, 3, 4) if mem == "pinned" else (2, 4, 6, 8)):
                     for mb in ((8, 24) if QUICK else (8, 16, 24, 48)):
                         ctx.set_option("tune_batch_pipe_mode", mode)

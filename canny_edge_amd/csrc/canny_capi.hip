@@ -120,6 +120,7 @@ struct canny_hip_ctx {
     // (launch_hyst_tail): no further launches, no host round trip, the call returns without waiting.
     // 1 (default) = for frames of up to kTailMaxTiles tiles, 0 = never (the multi-launch scheme with its poll)
     int hyst_tail = 1;
+    int hyst_tail_after = 2; // batch-wide sweeps before the tail kernel takes over (A/B: 2 or 3)
     bool hyst_iters_async = false; // last_hyst_iters has to be fetched from flags[0] (the tail path does not poll)
     // canny_hip_canny_batch: number of pipelines (host threads, each with an H2D, a compute and a D2H stream and a
     // ring of chunk slots) that each take every n-th chunk, and the chunk size (megabytes of input, or frames).
@@ -580,10 +581,11 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
             // runs the rest to convergence: everything is queued, nothing is waited for
             StageTimer tm(ctx, CANNY_HIP_STAGE_HYST_PROPAGATE);
             unsigned *sched = (unsigned *)ctx->stamps.p, *flags = (unsigned *)ctx->flags.p;
-            HIP_TRY(ctx, launch_hyst_propagate(S, C, sched, flags, 0, g, ctx->stream, d_edges, edge_value));
-            HIP_TRY(ctx, launch_hyst_propagate(S, C, sched, flags, 1, g, ctx->stream, d_edges, edge_value,
-                                               /*to_frame_queues=*/true));
-            HIP_TRY(ctx, launch_hyst_tail(S, C, sched, flags, 2, g, ctx->stream, d_edges, edge_value));
+            const int wide = ctx->hyst_tail_after;
+            for (int k = 0; k < wide; k++)
+                HIP_TRY(ctx, launch_hyst_propagate(S, C, sched, flags, k, g, ctx->stream, d_edges, edge_value,
+                                                   /*to_frame_queues=*/k == wide - 1));
+            HIP_TRY(ctx, launch_hyst_tail(S, C, sched, flags, wide, g, ctx->stream, d_edges, edge_value));
             ctx->hyst_iters_async = true;
             return CANNY_HIP_OK;
         }
@@ -857,6 +859,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "fuse_classify") && value <= 1) ctx->fuse_classify = value;
     else if (!std::strcmp(name, "smoothed_u8") && value <= 1) ctx->smoothed_u8 = value;
     else if (!std::strcmp(name, "hysteresis_tail") && value <= 1) ctx->hyst_tail = value;
+    else if (!std::strcmp(name, "tune_hyst_tail_after") && value >= 1 && value <= 4) ctx->hyst_tail_after = value;
     else if (!std::strcmp(name, "overlap_hysteresis") && value <= 1) ctx->overlap_hysteresis = value;
     else if (!std::strcmp(name, "tune_batch_workers") && value <= 16) ctx->batch_workers = value;
     else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) ctx->batch_chunk_mb = value;

@@ -309,10 +309,11 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 #pragma unroll
     for (int a = 0; a <= C; a++) {
         T[a] = t.tap[C - a];
-        // Keep the taps in VGPRs: a multiply with an SGPR operand is a slow-class instruction (~4.2 cycles of its
-        // pipe per wave against ~2.3 for v_mul_f32 v, v, v; tools/valu_issue_bench.hip), and every value is
-        // multiplied by C+1 of them.
-        asm volatile("" : "+v"(T[a]));
+        // The multiplying variant keeps the taps in VGPRs: a multiply with an SGPR operand is a slow-class instruction
+        // (tools/valu_issue_bench.hip) and that variant does 2(C+1) of them per value: 1.180 -> 1.086 ms per
+        // 128 x 4K together with the phased row pass.  The table variant multiplies only in the column pass and
+        // needs the six registers more: pinning them there costs a wave per SIMD (1.11 -> 1.25 ms).
+        if (!USE_LUT) asm volatile("" : "+v"(T[a]));
     }
 
     // weights: full window (wave-uniform) and, at the column borders, this lane's four own weights
@@ -378,23 +379,11 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         if (!ROW_EDGE || (r >= 0 && r < H)) {
             float Q[4][C + 1];
             if (USE_LUT) {
-                // GAUSS_LUT_TAPS (experiment): only the products with the LUT_N outermost taps are looked up, the
-                // others multiplied -- the table trades VALU issue for LDS cycles, and either can be the bound
-#ifndef GAUSS_LUT_TAPS
-#define GAUSS_LUT_TAPS 99
-#endif
-                constexpr int LUT_N = GAUSS_LUT_TAPS < C + 1 ? GAUSS_LUT_TAPS : C + 1;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const unsigned px = (cur >> (8 * i)) & 0xffu;
-                    const float *row = lut + px;
+                    const float *row = lut + ((cur >> (8 * i)) & 0xffu);
 #pragma unroll
-                    for (int a = C + 1 - LUT_N; a <= C; a++) Q[i][a] = row[a * 256];
-                    if (LUT_N < C + 1) {
-                        const float v = (float)px;
-#pragma unroll
-                        for (int a = 0; a < C + 1 - LUT_N; a++) Q[i][a] = __fmul_rn(v, T[a]);
-                    }
+                    for (int a = 0; a <= C; a++) Q[i][a] = row[a * 256];
                 }
             } else {
                 const float v[4] = {(float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
@@ -590,6 +579,7 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 // Live state per lane: 4(2C+1) open sums + 4(C+1) products + ~30; without an occupancy target the scheduler
 // interleaves several rows' products and doubles that.
 template <int C, bool USE_LUT, bool OUT_U8 = false>
+// (6 waves per SIMD spill: 2.05 ms against 1.05; 4 compile to the same code as 5 -- profiles/r02/ab4_*.txt)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 5 ? 5 : 4)))
 void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, int H, int W, int n_strips,
                       int n_segs, int seg_rows, int total_waves, GaussTaps t, int use_fma_div, float fma_c)

@@ -145,6 +145,14 @@ __device__ __forceinline__ int max_u16(int a, int b)
     return r;
 }
 
+// One row of results of a lane (16 or 8 bytes).  (A non-temporal hint on these stores measured no different:
+// profiles/r02/ab5_nt_stores.txt.)
+template <int NP>
+__device__ __forceinline__ void store_row(int16_t *dst, const uint32_t (&outp)[NP])
+{
+    __builtin_memcpy(dst, outp, 4 * NP);
+}
+
 template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, int NP, bool LDS_PLANES, bool IN_U8 = false>
 __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_mem, const uint4 *edge_lut = nullptr)
 {
@@ -174,20 +182,16 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
         for (int i = 0; i < NP; i++) p[i] = 0u;
         if (ROW_EDGE && (r < 0 || r >= H)) return; // wave-uniform: virtual rows are zero
         if (IN_U8) {
+            // p[0..1] receive the eight raw bytes; step() spreads them into s16 pairs when the row is USED, two rows
+            // later (expanding them here would make the load's consumer follow it directly: no prefetch left)
             const uint8_t *src8 = jb.fin8 + (size_t)r * W + x0;
             if (!COL_EDGE || full8) {
-                uint2 b;
-                __builtin_memcpy(&b, src8, 8); // one 8-byte load
-                // selector bytes: 0-3 pick a byte of the source, 0x0c yields 0x00
-                p[0] = __builtin_amdgcn_perm(b.x, b.x, 0x0c010c00u);
-                p[1] = __builtin_amdgcn_perm(b.x, b.x, 0x0c030c02u);
-                p[NP > 2 ? 2 : 0] = __builtin_amdgcn_perm(b.y, b.y, 0x0c010c00u);
-                p[NP > 2 ? 3 : 1] = __builtin_amdgcn_perm(b.y, b.y, 0x0c030c02u);
+                __builtin_memcpy(p, src8, 8); // one 8-byte load
             } else if (x0 + PX - 1 >= 0 && x0 < W) {
 #pragma unroll
                 for (int e = 0; e < PX; e++) {
                     int x = x0 + e;
-                    if (x >= 0 && x < W) p[e >> 1] |= (uint32_t)src8[e] << (16 * (e & 1));
+                    if (x >= 0 && x < W) p[e >> 2] |= (uint32_t)src8[e] << (8 * (e & 3));
                 }
             }
             return;
@@ -287,8 +291,19 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
     };
 
     // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
-    auto step = [&](auto ph, int r, const uint32_t (&p)[NP]) {
+    auto step = [&](auto ph, int r, const uint32_t (&praw)[NP]) {
         constexpr int PH = decltype(ph)::value;
+        uint32_t p[NP];
+        if (IN_U8) {
+            // selector bytes: 0-3 pick a byte of the source, 0x0c yields 0x00
+            p[0] = __builtin_amdgcn_perm(praw[0], praw[0], 0x0c010c00u);
+            p[1] = __builtin_amdgcn_perm(praw[0], praw[0], 0x0c030c02u);
+            p[NP > 2 ? 2 : 0] = __builtin_amdgcn_perm(praw[1], praw[1], 0x0c010c00u);
+            p[NP > 2 ? 3 : 1] = __builtin_amdgcn_perm(praw[1], praw[1], 0x0c030c02u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; i++) p[i] = praw[i];
+        }
         constexpr int k2 = PH % 3, k1 = (PH + 2) % 3, k0 = (PH + 1) % 3; // d/t of rows r, r-1, r-2
         constexpr int m2 = PH % 3, m1 = (PH + 2) % 3, m0 = (PH + 1) % 3; // M and bins of rows r-1, r-2, r-3
 
@@ -422,7 +437,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                     const unsigned rowoff = (unsigned)(y2 - ybeg) * kStagePitch;
                     stage[rowoff + stage_col] = (uint8_t)cbits; // halo lanes write pad columns nobody reads
                     stage[kStagePlane + rowoff + stage_col] = (uint8_t)sb;
-                    if (owner) __builtin_memcpy(jb.fout + (size_t)y2 * W + x0, outp, 4 * NP);
+                    if (owner) store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                 } else if (owner) { // W % 8 == 0: an owner lane's pixels are all inside the image
                     if (NP == 4 || (jb.lane & 1)) {
                         const unsigned bx = (unsigned)x0 >> 3;
@@ -431,12 +446,12 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                         jb.pconn[off] = (uint8_t)cbits;
                         jb.pstrong[off] = (uint8_t)sb;
                     }
-                    __builtin_memcpy(jb.fout + (size_t)y2 * W + x0, outp, 4 * NP);
+                    store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                 }
             } else if (owner) {
                 int16_t *dst = jb.fout + (size_t)y2 * W + x0;
                 if (!COL_EDGE || full8) {
-                    __builtin_memcpy(dst, outp, 4 * NP);
+                    store_row<NP>(dst, outp);
                 } else {
 #pragma unroll
                     for (int e = 0; e < PX; e++)

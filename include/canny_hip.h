@@ -108,7 +108,8 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *                    barrier between a frame's sweeps is all the ordering needed).  The call then queues five
  *                    kernels and returns without waiting: no per-sweep launches, no host round trip.  Used for
  *                    frames of up to 4096 tiles of 64x64 (a 4K frame has 2040); 0 = the multi-launch scheme whose
- *                    host polls for convergence
+ *                    host polls for convergence.  "tune_hyst_tail_after": 2 (default), 1..4 -- how many sweeps run
+ *                    batch-wide before the tail kernel takes over
  *   "overlap_hysteresis": 0 (default) / 1 -- canny() on 16 or more frames: the propagation sweeps of the first half
  *                    of the batch run on a second stream beside the Sobel+NMS kernel of the second half
  *                    (measured 1.5 % slower on 128 x 4K, kept for A/B)

@@ -736,3 +736,66 @@ def test_canny_large_resident_batch_of_4k_frames(hip):
         finally:
             c.free(d_in)
             c.free(d_out)
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 2: the per-frame tail kernel of the propagation, and the min_val > 255 domain
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tail", [1, 0], ids=["tail_kernel", "multi_launch"])
+def test_canny_hysteresis_tail_kernel(hip, tail):
+    """canny() finishes the propagation with ONE launch (a workgroup per frame loops over that frame's queue until it
+    stays empty).  Frames of very different depth in one batch -- serpentines that need hundreds of sweeps next to
+    frames that need two -- several shapes (one tile, one tile row, many tiles), and repeated calls on the same
+    context; `hysteresis_tail` = 0 is the multi-launch scheme with the host poll.  Both against the oracle."""
+    with hip.Context(0) as c:
+        c.set_option("hysteresis_tail", tail)
+        for h, w, n in ((200, 328, 9), (64, 64, 3), (40, 1000, 4), (2, 8, 2), (330, 136, 5)):
+            frames = np.stack([_mixed(h, w, 500 + i) for i in range(n)])
+            if h >= 40:
+                frames[1] = _serpentine_image(h, w)
+                frames[n - 1] = _serpentine_image(h, w)[::-1, ::-1].copy()
+            want = np.stack([oracle.canny(f, 0.3, 50, 250) for f in frames])
+            d_in, d_out = c.malloc(frames.nbytes), c.malloc(frames.nbytes * 2)
+            try:
+                c.h2d(d_in, frames)
+                for rep in range(2):
+                    c.dev_canny(d_in, 0.3, 50, 250, h, w, n, d_out)
+                    got = np.empty(frames.shape, np.int16)
+                    c.d2h(got, d_out)
+                    bad = np.argwhere(got != want)
+                    assert bad.size == 0, (tail, h, w, n, rep, bad[:5].tolist())
+                if h == 200:
+                    assert c.last_hysteresis_iterations > 8  # the serpentine really needs a long walk
+            finally:
+                c.free(d_in)
+                c.free(d_out)
+
+
+def test_canny_frames_beyond_the_tail_kernels_tile_limit(hip):
+    """More than 4096 tiles per frame: the propagation goes back to the multi-launch scheme (one workgroup per
+    frame would be too few).  64 rows x 262,208 columns = 1 x 4097 tiles."""
+    h, w = 64, 64 * 4097
+    img = _mixed(h, w, 77)
+    with hip.Context(0) as c:
+        assert np.array_equal(c.canny(img, 1.0, 50, 150), oracle.canny(img, 1.0, 50, 150))
+
+
+def test_thresholds_above_edge_value_are_a_domain_error(ctx, hip):
+    """min_val > 255 >= max_val: the reference overwrites reached pixels with EDGE = 255 while its scan is still
+    running, so a reached pixel the scan has not passed yet fails `< minVal` and is zeroed again
+    (src/utils.cpp:327-334): the result depends on the scan order."""
+    a = np.array([[300, 300, 0, 0], [0, 0, 0, 0]], np.int16)
+    assert oracle.hysteresis(a, 300, 100).ravel().tolist() == [255, 0, 0, 0, 0, 0, 0, 0]  # what the reference does
+    with pytest.raises(hip.CannyHipError) as ei:
+        ctx.hysteresis(a, 300, 100)
+    assert ei.value.status == 5
+    with pytest.raises(hip.CannyHipError) as ei:
+        ctx.canny(_mixed(16, 16, 1), 1.0, 300, 100)
+    assert ei.value.status == 5
+    with pytest.raises(hip.CannyHipError) as ei:
+        ctx.find_edge_pixels(a, np.zeros(a.shape, np.uint8), 0, 300, 400)
+    assert ei.value.status == 5
+    # both thresholds above 255: everything ends as 0 whatever the order -- accepted, and equal to the oracle
+    assert np.array_equal(ctx.hysteresis(a, 300, 400), oracle.hysteresis(a, 300, 400))
+    img = _mixed(24, 40, 3)
+    assert np.array_equal(ctx.canny(img, 1.0, 300, 400), oracle.canny(img, 1.0, 300, 400))

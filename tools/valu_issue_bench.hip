@@ -527,6 +527,68 @@ DEF_KERNEL1(swizzle_plus_3_plain, SW4(0, 1, 2, 3) SW4(4, 5, 6, 7) SW4(8, 9, 10, 
 #define SW8(a, b, c, d, e, f, g, h) "ds_swizzle_b32 %" #a ", %" #a " offset:swizzle(SWAP,1)\n\tv_mul_f32 %" #b ", %" #b ", %17\n\tv_add_f32 %" #c ", %" #c ", %17\n\tv_add_f32 %" #d ", %" #d ", %16\n\t" PLAIN4(e, f, g, h)
 DEF_KERNEL1(swizzle_plus_7_plain, SW8(0, 1, 2, 3, 4, 5, 6, 7) SW8(8, 9, 10, 11, 12, 13, 14, 15) SW8(0, 1, 2, 3, 4, 5, 6, 7) SW8(8, 9, 10, 11, 12, 13, 14, 15) SW8(0, 1, 2, 3, 4, 5, 6, 7) SW8(8, 9, 10, 11, 12, 13, 14, 15) SW8(0, 1, 2, 3, 4, 5, 6, 7) SW8(8, 9, 10, 11, 12, 13, 14, 15) "s_waitcnt lgkmcnt(0)\n\t")
 
+
+// ---- third batch: explicit registers.  Is the 2.3-cycle rate tied to the in-place form (dst == src0) or to the VGPR
+// banks (register number mod 4) of the operands?  Registers v64..v127 are clobbered explicitly.
+#define CLOB64 "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127"
+#define DEF_KERNEL_X(NAME, BODY)                                                                     \
+    __global__ void __launch_bounds__(1024) k_##NAME(Stamp *stamps, unsigned *sink, int iters)       \
+    {                                                                                                \
+        extern __shared__ unsigned lds[];                                                            \
+        for (unsigned i = threadIdx.x; i < 2048; i += blockDim.x) lds[i] = i;                        \
+        __syncthreads();                                                                             \
+        unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                    \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();                                        \
+        for (int it = 0; it < iters; it++) {                                                         \
+            asm volatile(BODY BODY BODY BODY ::: "memory", CLOB64);                                  \
+        }                                                                                            \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();                                        \
+        unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                    \
+        unsigned acc;                                                                                \
+        asm volatile("v_mov_b32 %0, v64" : "=v"(acc)::CLOB64);                                       \
+        if (acc == 0x12345u) sink[0] = acc;                                                          \
+        if ((threadIdx.x & 63) == 0) {                                                               \
+            unsigned hw, xcc;                                                                        \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                         \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                       \
+            Stamp s{t0, t1, r0, r1, hw, xcc};                                                        \
+            stamps[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = s;                           \
+        }                                                                                            \
+    }
+// 16 instructions per BODY; dst v64+4k+b..., sources chosen per test.  R(op, d, a, b) -> "op vD, vA, vB"
+#define R3(op, d, a, b) op " v" #d ", v" #a ", v" #b "\n\t"
+// in place, sources in different banks:        d = d op (reg in another bank)
+#define X_INPLACE(op) R3(op,64,64,81) R3(op,65,65,82) R3(op,66,66,83) R3(op,67,67,80) R3(op,68,68,85) R3(op,69,69,86) R3(op,70,70,87) R3(op,71,71,84) R3(op,72,72,89) R3(op,73,73,90) R3(op,74,74,91) R3(op,75,75,88) R3(op,76,76,93) R3(op,77,77,94) R3(op,78,78,95) R3(op,79,79,92)
+// three different registers, three different banks (dst bank k, src0 bank k+1, src1 bank k+2)
+#define X_3REG_3BANK(op) R3(op,64,81,98) R3(op,65,82,99) R3(op,66,83,96) R3(op,67,80,97) R3(op,68,85,102) R3(op,69,86,103) R3(op,70,87,100) R3(op,71,84,101) R3(op,72,89,106) R3(op,73,90,107) R3(op,74,91,104) R3(op,75,88,105) R3(op,76,93,110) R3(op,77,94,111) R3(op,78,95,108) R3(op,79,92,109)
+// three different registers, the two SOURCES in the same bank
+#define X_SRC_SAME_BANK(op) R3(op,64,81,97) R3(op,65,82,98) R3(op,66,83,99) R3(op,67,80,96) R3(op,68,85,101) R3(op,69,86,102) R3(op,70,87,103) R3(op,71,84,100) R3(op,72,89,105) R3(op,73,90,106) R3(op,74,91,107) R3(op,75,88,104) R3(op,76,93,109) R3(op,77,94,110) R3(op,78,95,111) R3(op,79,92,108)
+// three different registers, dst in the same bank as src0
+#define X_DST_SRC0_BANK(op) R3(op,64,80,97) R3(op,65,81,98) R3(op,66,82,99) R3(op,67,83,96) R3(op,68,84,101) R3(op,69,85,102) R3(op,70,86,103) R3(op,71,87,100) R3(op,72,88,105) R3(op,73,89,106) R3(op,74,90,107) R3(op,75,91,104) R3(op,76,92,109) R3(op,77,93,110) R3(op,78,94,111) R3(op,79,95,108)
+// dependent on the instruction just before (dst of i is src0 of i+1), not in place
+#define X_CHAIN(op) R3(op,64,79,81) R3(op,65,64,82) R3(op,66,65,83) R3(op,67,66,80) R3(op,68,67,85) R3(op,69,68,86) R3(op,70,69,87) R3(op,71,70,84) R3(op,72,71,89) R3(op,73,72,90) R3(op,74,73,91) R3(op,75,74,88) R3(op,76,75,93) R3(op,77,76,94) R3(op,78,77,95) R3(op,79,78,92)
+DEF_KERNEL_X(x_add_inplace, X_INPLACE("v_add_f32"))
+DEF_KERNEL_X(x_add_3reg_3bank, X_3REG_3BANK("v_add_f32"))
+DEF_KERNEL_X(x_add_src_same_bank, X_SRC_SAME_BANK("v_add_f32"))
+DEF_KERNEL_X(x_add_dst_src0_bank, X_DST_SRC0_BANK("v_add_f32"))
+DEF_KERNEL_X(x_add_chain, X_CHAIN("v_add_f32"))
+DEF_KERNEL_X(x_mul_3reg_3bank, X_3REG_3BANK("v_mul_f32"))
+DEF_KERNEL_X(x_maxu16_3reg_3bank, X_3REG_3BANK("v_max_u16"))
+DEF_KERNEL_X(x_maxu16_src_same_bank, X_SRC_SAME_BANK("v_max_u16"))
+DEF_KERNEL_X(x_maxi32_3reg_3bank, X_3REG_3BANK("v_max_i32"))
+DEF_KERNEL_X(x_pksub_3reg_3bank, X_3REG_3BANK("v_pk_sub_i16"))
+DEF_KERNEL_X(x_and_3reg_3bank, X_3REG_3BANK("v_and_b32"))
+DEF_KERNEL_X(x_addu32_3reg_3bank, X_3REG_3BANK("v_add_u32"))
+// 4-operand forms: d, a, b, c
+#define R4(op, d, a, b, c) op " v" #d ", v" #a ", v" #b ", v" #c "\n\t"
+#define X4_4BANK(op) R4(op,64,81,98,115) R4(op,65,82,99,112) R4(op,66,83,96,113) R4(op,67,80,97,114) R4(op,68,85,102,119) R4(op,69,86,103,116) R4(op,70,87,100,117) R4(op,71,84,101,118) R4(op,72,89,106,123) R4(op,73,90,107,120) R4(op,74,91,104,121) R4(op,75,88,105,122) R4(op,76,93,110,127) R4(op,77,94,111,124) R4(op,78,95,108,125) R4(op,79,92,109,126)
+#define X4_ACC(op) R4(op,64,81,98,64) R4(op,65,82,99,65) R4(op,66,83,96,66) R4(op,67,80,97,67) R4(op,68,85,102,68) R4(op,69,86,103,69) R4(op,70,87,100,70) R4(op,71,84,101,71) R4(op,72,89,106,72) R4(op,73,90,107,73) R4(op,74,91,104,74) R4(op,75,88,105,75) R4(op,76,93,110,76) R4(op,77,94,111,77) R4(op,78,95,108,78) R4(op,79,92,109,79)
+DEF_KERNEL_X(x_fma_4reg_4bank, X4_4BANK("v_fma_f32"))
+DEF_KERNEL_X(x_fma_acc, X4_ACC("v_fma_f32"))
+DEF_KERNEL_X(x_max3_4reg_4bank, X4_4BANK("v_max3_i32"))
+DEF_KERNEL_X(x_pkmad_4reg_4bank, X4_4BANK("v_pk_mad_i16"))
+DEF_KERNEL_X(x_pkfma_4bank, "v_pk_fma_f32 v[64:65], v[82:83], v[100:101], v[118:119]\n\tv_pk_fma_f32 v[66:67], v[84:85], v[102:103], v[120:121]\n\tv_pk_fma_f32 v[68:69], v[86:87], v[104:105], v[122:123]\n\tv_pk_fma_f32 v[70:71], v[88:89], v[106:107], v[124:125]\n\tv_pk_fma_f32 v[72:73], v[90:91], v[108:109], v[126:127]\n\tv_pk_fma_f32 v[74:75], v[92:93], v[110:111], v[112:113]\n\tv_pk_fma_f32 v[76:77], v[94:95], v[96:97], v[114:115]\n\tv_pk_fma_f32 v[78:79], v[80:81], v[98:99], v[116:117]\n\tv_pk_fma_f32 v[64:65], v[82:83], v[100:101], v[118:119]\n\tv_pk_fma_f32 v[66:67], v[84:85], v[102:103], v[120:121]\n\tv_pk_fma_f32 v[68:69], v[86:87], v[104:105], v[122:123]\n\tv_pk_fma_f32 v[70:71], v[88:89], v[106:107], v[124:125]\n\tv_pk_fma_f32 v[72:73], v[90:91], v[108:109], v[126:127]\n\tv_pk_fma_f32 v[74:75], v[92:93], v[110:111], v[112:113]\n\tv_pk_fma_f32 v[76:77], v[94:95], v[96:97], v[114:115]\n\tv_pk_fma_f32 v[78:79], v[80:81], v[98:99], v[116:117]\n\t")
+
 typedef void (*kernel_t)(Stamp *, unsigned *, int);
 struct Test {
     const char *name;
@@ -629,6 +691,25 @@ static const Test kTests[] = {
     {"52 plain, 12 DPP adds spread singly", k_dpp_spread_52_12, 64, ""},
     {"plain VALU, every 4th with an SGPR operand", k_sgpr_every_4th, 64, ""},
     {"plain VALU, every 8th a v_cvt_i32_f32", k_cvt_every_8th, 64, ""},
+    // ---- third batch (explicit registers) ----
+    {"v_max_f32", k_max_f32, 64, ""},
+    {"v_add_f32 in place, other bank", k_x_add_inplace, 64, "d = d + x"},
+    {"v_add_f32 3 regs, 3 banks", k_x_add_3reg_3bank, 64, "d = a + b"},
+    {"v_add_f32 3 regs, sources share a bank", k_x_add_src_same_bank, 64, ""},
+    {"v_add_f32 3 regs, dst shares src0's bank", k_x_add_dst_src0_bank, 64, ""},
+    {"v_add_f32 3 regs, chain (src0 = previous dst)", k_x_add_chain, 64, ""},
+    {"v_mul_f32 3 regs, 3 banks", k_x_mul_3reg_3bank, 64, ""},
+    {"v_max_u16 3 regs, 3 banks", k_x_maxu16_3reg_3bank, 64, ""},
+    {"v_max_u16 3 regs, sources share a bank", k_x_maxu16_src_same_bank, 64, ""},
+    {"v_max_i32 3 regs, 3 banks", k_x_maxi32_3reg_3bank, 64, ""},
+    {"v_pk_sub_i16 3 regs, 3 banks", k_x_pksub_3reg_3bank, 64, ""},
+    {"v_and_b32 3 regs, 3 banks", k_x_and_3reg_3bank, 64, ""},
+    {"v_add_u32 3 regs, 3 banks", k_x_addu32_3reg_3bank, 64, ""},
+    {"v_fma_f32 4 regs, 4 banks", k_x_fma_4reg_4bank, 64, ""},
+    {"v_fma_f32 accumulate (d = a*b + d)", k_x_fma_acc, 64, ""},
+    {"v_max3_i32 4 regs, 4 banks", k_x_max3_4reg_4bank, 64, ""},
+    {"v_pk_mad_i16 4 regs, 4 banks", k_x_pkmad_4reg_4bank, 64, ""},
+    {"v_pk_fma_f32 register pairs", k_x_pkfma_4bank, 64, ""},
 };
 
 struct Result {

@@ -11,8 +11,9 @@ import numpy as np
 
 
 def synth_frame(height: int, width: int, seed: int = 42) -> np.ndarray:
-    """Return a uint8 [height, width] frame; the same (shape, seed) always gives the same bytes."""
-    rng = np.random.default_rng(seed)
+    """Return a uint8 [height, width] frame; the same (shape, seed) always gives the same bytes.
+    The generator is the Mersenne Twister SURVEY.md 8(d) names (mt19937, seed 42 + i for frame i)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
     img = np.full((height, width), 30, dtype=np.int16)
     n_rect = (height * width) // 8000 + 4
     max_w = max(9, width // 6)

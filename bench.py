@@ -155,7 +155,25 @@ def host_to_host(ctx, np, base_np, args, rank, world, sync_max, check):
         t = sync_max(time.perf_counter() - t0)
         res["s16_pageable"] = {"value": round(pg_in.size * world / t / 1e6, 1), "unit": "Mpixels/s",
                                "frames_per_gpu": int(pg_in.shape[0]), "ms_per_batch": round(t * 1e3, 3)}
+        # the same caller-allocated buffers page-locked once with canny_hip_host_register (what a maintainer of the
+        # reference would do with its new[] frames): the pinned path
+        t0 = time.perf_counter()
+        ctx.host_register(pg_in)
+        ctx.host_register(pg_out)
+        t_reg = time.perf_counter() - t0
+        try:
+            ctx.canny_batch(pg_in, args.sigma, args.min_val, args.max_val, out=pg_out)
+            t0 = time.perf_counter()
+            ctx.canny_batch(pg_in, args.sigma, args.min_val, args.max_val, out=pg_out)
+            t = sync_max(time.perf_counter() - t0)
+        finally:
+            ctx.host_unregister(pg_in)
+            ctx.host_unregister(pg_out)
+        res["s16_registered"] = {"value": round(pg_in.size * world / t / 1e6, 1), "unit": "Mpixels/s",
+                                 "frames_per_gpu": int(pg_in.shape[0]), "ms_per_batch": round(t * 1e3, 3),
+                                 "register_ms_once": round(t_reg * 1e3, 2)}
     res["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES")
+    res["cpus_of_this_process"] = len(os.sched_getaffinity(0))
     return res
 
 
@@ -184,9 +202,10 @@ def main():
     from canny_edge_amd import capi, sharding
     from canny_edge_amd.synth import synth_frame
 
-    # one process per GPU: run (and first-touch the pinned buffers) on the CPUs local to this rank's GPU
+    # one process per GPU: run (and first-touch host buffers) on the CPUs local to this rank's GPU -- a buffer on the other
+    # socket costs the host->host pipeline a third to a half of the PCIe rate
     local_cpus = capi.device_local_cpus(local_rank)
-    if local_cpus and world > 1:
+    if local_cpus:
         try:
             cpus = set()
             for part in local_cpus.split(","):
@@ -406,6 +425,7 @@ def main():
     h2h = None
     if args.h2h_frames > 0:
         h2h = host_to_host(ctx, np, base_np, args, rank, world, sync_max, check=(not args.no_check and rank == 0))
+        h2h["gpu_local_cpus"] = local_cpus
 
     out = {
         "metric": "Mpixels/s end-to-end Canny (4K gray); % HBM roofline on Sobel+NMS",

@@ -45,7 +45,7 @@ EXPORTS = (
     "canny_hip_selftest_mag_angle", "canny_hip_selftest_div", "canny_hip_selftest_div_fma",
     "canny_hip_selftest_div_fma_table", "canny_hip_canny_multi_gpu_u8", "canny_hip_multi_gpu_set_option",
     "canny_hip_multi_gpu_release", "canny_hip_device_local_cpus", "canny_hip_selftest_cpulist_count",
-    "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in",
+    "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in", "canny_hip_host_register", "canny_hip_host_unregister",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -87,6 +87,8 @@ def load() -> C.CDLL:
         "canny_hip_free": ([p, p], i),
         "canny_hip_host_alloc": ([p, pp, sz], i),
         "canny_hip_host_free": ([p, p], i),
+        "canny_hip_host_register": ([p, p, sz], i),
+        "canny_hip_host_unregister": ([p, p], i),
         "canny_hip_memcpy_h2d": ([p, p, p, sz], i),
         "canny_hip_memcpy_d2h": ([p, p, p, sz], i),
         "canny_hip_gaussian_kernel": ([f, p, i, ip], i),
@@ -319,6 +321,14 @@ class Context:
         self._pinned.append(p.value)
         buf = (C.c_uint8 * nbytes).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def host_register(self, a: np.ndarray):
+        """Page-lock an ordinary (C-contiguous) numpy array in place: canny_batch then DMA's it like pinned memory."""
+        assert a.flags["C_CONTIGUOUS"]
+        self._check(self._L.canny_hip_host_register(self._h, _hp(a), a.nbytes), "host_register")
+
+    def host_unregister(self, a: np.ndarray):
+        self._check(self._L.canny_hip_host_unregister(self._h, _hp(a)), "host_unregister")
 
     def canny_batch(self, imgs, sigma: float, min_val: int, max_val: int, out: Optional[np.ndarray] = None,
                     u8: bool = False) -> np.ndarray:

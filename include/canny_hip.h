@@ -148,6 +148,11 @@ int canny_hip_malloc(canny_hip_ctx *ctx, void **dev_ptr, size_t bytes);
 int canny_hip_free(canny_hip_ctx *ctx, void *dev_ptr);
 int canny_hip_host_alloc(canny_hip_ctx *ctx, void **host_ptr, size_t bytes); /* pinned */
 int canny_hip_host_free(canny_hip_ctx *ctx, void *host_ptr);
+/* Page-locks / releases memory the caller allocated itself (the reference's frames are `new[]` arrays and cv::Mat
+ * data, src/main.cpp:111-137): registered buffers are DMA'd in place by the batch entry points, exactly like
+ * canny_hip_host_alloc memory.  Register once, not per call (~22 ms per GB). */
+int canny_hip_host_register(canny_hip_ctx *ctx, void *host_ptr, size_t bytes);
+int canny_hip_host_unregister(canny_hip_ctx *ctx, void *host_ptr);
 int canny_hip_memcpy_h2d(canny_hip_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int canny_hip_memcpy_d2h(canny_hip_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 

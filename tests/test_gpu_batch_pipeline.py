@@ -170,6 +170,32 @@ def test_multi_gpu_pinned_buffers_and_repeat_calls(hip, batch_270):
         hip.multi_gpu_release()
 
 
+def test_batch_on_registered_caller_memory(hip, batch_270):
+    """Memory the caller allocated itself (the reference's frames are new[] arrays), page-locked with
+    canny_hip_host_register: the pinned path of the pipeline, then unregistered: the staging path again."""
+    frames, want = batch_270
+    src = frames.copy()
+    dst = np.full(frames.shape, -1, np.int16)
+    with hip.Context(0) as ctx:
+        ctx.set_option("tune_batch_chunk_frames", 5)
+        ctx.host_register(src)
+        ctx.host_register(dst)
+        try:
+            ctx.canny_batch(src, SIGMA, LO, HI, out=dst)
+            _assert_frames_equal(dst, want, "registered buffers")
+            dst[...] = -1
+            ctx.canny_batch(src, SIGMA, LO, HI, out=dst)
+            _assert_frames_equal(dst, want, "registered buffers, second call")
+        finally:
+            ctx.host_unregister(src)
+            ctx.host_unregister(dst)
+        dst[...] = -1
+        ctx.canny_batch(src, SIGMA, LO, HI, out=dst)
+        _assert_frames_equal(dst, want, "after unregistering")
+        with pytest.raises(hip.CannyHipError):
+            ctx.host_unregister(src)  # not registered any more
+
+
 def test_batch_true_size_1024_frames_of_1080p(hip):
     """BASELINE config 3 at its real size: 1024 x 1920x1080, sigma 1.0, 16 distinct frames cycled, every one of the
     1024 output frames compared with its oracle map (pinned buffers, default tuning, s16 then u8)."""

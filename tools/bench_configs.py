@@ -46,8 +46,15 @@ def main():
     def dev_once():
         ctx.dev_canny(d_in, 1.4, 50, 150, H, W, 1, d_out)
         ctx.synchronize()
-    t_dev = timed(dev_once, 20)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.5:  # clocks up (as bench.py's --spinup-seconds)
+        ctx.dev_canny(d_in, 1.4, 50, 150, H, W, 1, d_out)
+    ctx.synchronize()
+    t_dev = timed(dev_once, 50)
     t_host = timed(lambda: ctx.canny(img, 1.4, 50, 150), 5)
+    pin1_in, pin1_out = ctx.pinned_array((1, H, W), np.uint8), ctx.pinned_array((1, H, W), np.int16)
+    pin1_in[0] = img
+    t_host_pinned = timed(lambda: ctx.canny_batch(pin1_in, 1.4, 50, 150, out=pin1_out), 20)
 
     # a stream of single frames (the reference's capture loop), blocking calls vs canny_hip_dev_canny_stream
     d_out2 = ctx.malloc(img.nbytes * 2)
@@ -72,6 +79,7 @@ def main():
     out["C2_single_4k_sigma1.4"] = {
         "device_resident_ms": round(t_dev * 1e3, 4), "device_resident_Mpix_s": round(H * W / t_dev / 1e6, 1),
         "host_to_host_ms": round(t_host * 1e3, 3), "host_to_host_Mpix_s": round(H * W / t_host / 1e6, 1),
+        "host_to_host_pinned_ms": round(t_host_pinned * 1e3, 4),
         "hysteresis_sweeps": ctx.last_hysteresis_iterations}
     ctx.free(d_in)
     ctx.free(d_out)
@@ -129,9 +137,14 @@ def main():
             ctx.synchronize()
         t_dev = timed(dev16, 5)
         t_host = timed(lambda: ctx.canny(img, 2.0, 50, 150), 1)
+        pin_in = ctx.pinned_array((1, H, W), np.uint8)
+        pin_out = ctx.pinned_array((1, H, W), np.int16)
+        pin_in[0] = img
+        t_pin = timed(lambda: ctx.canny_batch(pin_in, 2.0, 50, 150, out=pin_out), 3)
         out["C4_single_16k_sigma2.0"] = {
             "device_resident_ms": round(t_dev * 1e3, 3), "device_resident_Mpix_s": round(H * W / t_dev / 1e6, 1),
             "host_to_host_ms": round(t_host * 1e3, 2), "host_to_host_Mpix_s": round(H * W / t_host / 1e6, 1),
+            "host_to_host_pinned_ms": round(t_pin * 1e3, 2), "host_to_host_pinned_Mpix_s": round(H * W / t_pin / 1e6, 1),
             "hysteresis_sweeps": ctx.last_hysteresis_iterations}
         ctx.free(d_in)
         ctx.free(d_out)

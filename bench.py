@@ -424,7 +424,9 @@ def main():
 
     h2h = None
     if args.h2h_frames > 0:
+        ctx.set_stream(0)  # the context's own non-blocking stream: torch's current stream is the legacy default stream
         h2h = host_to_host(ctx, np, base_np, args, rank, world, sync_max, check=(not args.no_check and rank == 0))
+        ctx.set_stream(stream.cuda_stream)
         h2h["gpu_local_cpus"] = local_cpus
 
     out = {

@@ -1288,7 +1288,8 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         const int my_chunks = (n_chunks - wid + n_workers - 1) / n_workers;
         const size_t in_bytes = frame_px * chunk, out_bytes = frame_px * chunk * out_elem;
         hipError_t e = hipSuccess;
-        for (int k = 0; k < std::min(my_chunks, (int)Pipe::kSlots) && e == hipSuccess; k++) {
+        constexpr int n_slots = Pipe::kSlots;
+        for (int k = 0; k < std::min(my_chunks, n_slots) && e == hipSuccess; k++) {
             Pipe::Slot &S = P.slot[k];
             S.d2h_issued = false;
             S.retire_dst = nullptr;
@@ -1311,12 +1312,12 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         };
         // host -> d_in of chunk j
         auto upload = [&](int j) -> hipError_t {
-            Pipe::Slot &S = P.slot[j % Pipe::kSlots];
+            Pipe::Slot &S = P.slot[j % n_slots];
             int f0, nf;
             chunk_range(j, f0, nf);
             const unsigned char *src = imgs + (size_t)f0 * frame_px;
             hipError_t err = hipSuccess;
-            if (j >= Pipe::kSlots) {
+            if (j >= n_slots) {
                 // the slot's previous user (chunk j - kSlots): its kernels must have read d_in (dev_canny no longer
                 // blocks the host), and its upload must have left pin_in
                 err = hipStreamWaitEvent(s_h2d, S.ev_comp, 0);
@@ -1333,7 +1334,7 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         };
         // the staged output of chunk j reaches the caller's pageable buffer
         auto retire = [&](int j) -> hipError_t {
-            Pipe::Slot &S = P.slot[j % Pipe::kSlots];
+            Pipe::Slot &S = P.slot[j % n_slots];
             if (!S.retire_dst) return hipSuccess;
             hipError_t err = hipEventSynchronize(S.ev_d2h);
             if (err == hipSuccess) std::memcpy(S.retire_dst, S.pin_out.p, S.retire_bytes);
@@ -1343,7 +1344,7 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         const char *where = "batch H2D";
         e = upload(0);
         for (int j = 0; j < my_chunks && e == hipSuccess && st == CANNY_HIP_OK; j++) {
-            Pipe::Slot &S = P.slot[j % Pipe::kSlots];
+            Pipe::Slot &S = P.slot[j % n_slots];
             int f0, nf;
             chunk_range(j, f0, nf);
             if (j + 1 < my_chunks && (e = upload(j + 1)) != hipSuccess) break;
@@ -1362,6 +1363,14 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
                 d_res = S.d_out8.p;
             }
             if ((e = hipEventRecord(S.ev_comp, sub->stream)) != hipSuccess) break;
+            // The HOST waits for chunk j's kernels here (its next upload is already queued).  canny() itself no longer
+            // blocks, and a host that runs ahead by the whole batch -- a thousand queued copies, kernels and event
+            // waits -- makes the runtime slower per chunk and erratic: 1024 x 1080p in 24 MB chunks 18.7 Gpix/s
+            // against 25.5 with a third as many 64 MB chunks, 128 x 4K anywhere between 19 and 25.4 from run to run.
+            // One chunk of run-ahead is what the blocking canny() of the first version of this pipeline gave it,
+            // and what measured best and steadiest (profiles/r02/c3_sweep_*.txt, pipe_patterns.txt "P2b"); letting
+            // the host run five chunks ahead kept the s16 rate but made the u8 rate erratic (27-44 ms per 128 x 4K).
+            if ((e = hipEventSynchronize(S.ev_comp)) != hipSuccess) break;
             // download of chunk j (pin_out of this slot was retired kSlots - 1 iterations ago)
             where = "batch D2H";
             unsigned char *dst = (unsigned char *)edges + (size_t)f0 * frame_px * out_elem;

@@ -27,7 +27,7 @@ The JSON line also carries
   host_to_host -- SURVEY.md 8(d) Metric 1 as the reference's GPU path pays it (src/cuda.cu:83-101: every frame
                   crosses PCIe both ways): --h2h-frames 4K frames from pinned host memory through
                   canny_hip_canny_batch (s16 maps, the reference's plane type) and canny_hip_canny_batch_u8, wall
-                  time including H2D and D2H, GB/s per direction against the PCIe 5 x16 link (63 GB/s spec), a single
+                  time of the median call including H2D and D2H, GB/s per direction against the PCIe 5 x16 link (63 GB/s spec), a single
                   frame's latency, and the pageable-buffer rate.  `value` itself stays DEVICE-RESIDENT (`scope`).
   cpu_baseline -- the CPU oracle (a faithful single-thread restatement of the reference's utils.cpp;
                   the reference itself cannot be compiled here) timed on a bounded sample, rank 0, N=1
@@ -72,7 +72,7 @@ def parse():
                          "step; 200: 2.40)")
     ap.add_argument("--h2h-frames", type=int, default=128,
                     help="frames per host-to-host batch (pinned host u8 in -> pinned host edge maps out); 0 skips it")
-    ap.add_argument("--h2h-reps", type=int, default=3)
+    ap.add_argument("--h2h-reps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the pre-timing parity spot check")
     return ap.parse_args()
@@ -109,7 +109,7 @@ def host_to_host(ctx, np, base_np, args, rank, world, sync_max, check):
     res = {"frames_per_gpu": n, "height": H, "width": W, "sigma": args.sigma, "reps": args.h2h_reps,
            "pcie_peak_GBps_per_direction": PCIE_PEAK_GBS,
            "what": "canny_hip_canny_batch / _u8 on pinned host buffers: 3-stream chunk pipeline "
-                   "(upload | kernels | download), wall time per call, MAX over ranks"}
+                   "(upload | kernels | download), wall time of the median of --h2h-reps calls, MAX over ranks"}
     if True:  # the bench's own context: its stream is idle here, and every extra stream costs a hardware queue
         src = ctx.pinned_array((n, H, W), np.uint8)
         for i in range(n):
@@ -118,14 +118,18 @@ def host_to_host(ctx, np, base_np, args, rank, world, sync_max, check):
         for name, out in outs.items():
             u8 = name == "u8"
             out[...] = 1
-            ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8)  # builds pipelines, staging
-            sync_max(0.0)
-            t0 = time.perf_counter()
-            for _ in range(args.h2h_reps):
+            for _ in range(2):  # builds pipelines and staging; lets the link clocks settle after the compute phase
                 ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8)
-            t = sync_max((time.perf_counter() - t0) / args.h2h_reps)
+            sync_max(0.0)
+            calls = []
+            for _ in range(args.h2h_reps):  # every call timed; the figure is the MEDIAN call (MAX over ranks)
+                t0 = time.perf_counter()
+                ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8)
+                calls.append(time.perf_counter() - t0)
+            t = sync_max(sorted(calls)[len(calls) // 2])
             h2d, d2h = px / t / 1e9, px * out.itemsize / t / 1e9
             res[name] = {"value": round(px * world / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_batch": round(t * 1e3, 3),
+                         "ms_per_call": [round(c * 1e3, 2) for c in calls],
                          "h2d_GBps_per_gpu": round(h2d, 2), "d2h_GBps_per_gpu": round(d2h, 2),
                          "link_frac": round(max(h2d, d2h) / PCIE_PEAK_GBS, 4),
                          "bytes_over_link_per_px": 1 + out.itemsize}

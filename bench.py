@@ -198,10 +198,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the Canny hot path has no CPU fallback")
+    # CANNY_BENCH_REHEARSE=1: a dry run of the N-rank code path on a box with fewer GPUs than ranks -- ranks share the
+    # cards round-robin and rendezvous over gloo (RCCL refuses two ranks on one device).  Its numbers mean nothing and the
+    # line says so ("rehearsal": true); the driver never sets it.
+    rehearse = os.environ.get("CANNY_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = None if rehearse else dev  # where the MAX-over-ranks tensor lives
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from canny_edge_amd import capi, sharding
     from canny_edge_amd.synth import synth_frame
@@ -297,7 +307,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        elapsed = sharding.max_over_ranks(elapsed, dev)
+        elapsed = sharding.max_over_ranks(elapsed, red_dev)
 
     sn_ms_total, sn_launches = ctx.profile_get(capi.STAGE_SOBEL_NMS)
     ctx.set_option("profile_stage_mask", 0)  # all stages
@@ -333,7 +343,7 @@ def main():
         el_plain = time.perf_counter() - t1
         if world > 1:
             dist.barrier()
-            el_plain = sharding.max_over_ranks(el_plain, dev)
+            el_plain = sharding.max_over_ranks(el_plain, red_dev)
         plain = {"value": round(sharding.aggregate_throughput(px_per_step * args.steps, world, el_plain) / 1e6, 1),
                  "unit": "Mpixels/s", "ms_per_step": round(el_plain / args.steps * 1e3, 4),
                  "what": "same workload through canny_hip_dev_canny (no overlap between consecutive steps)"}
@@ -423,7 +433,7 @@ def main():
     def sync_max(t):
         if world > 1:
             dist.barrier()
-            return sharding.max_over_ranks(t, dev)
+            return sharding.max_over_ranks(t, red_dev)
         return t
 
     h2h = None
@@ -446,7 +456,8 @@ def main():
                    "frames_per_gpu": F, "height": H, "width": W, "sigma": args.sigma,
                    "calls": ("canny_hip_dev_canny_stream: the host checks step i's convergence after queueing the "
                              "Gaussian of step i+1; all K steps complete inside the timed region") if args.stream
-                   else "canny_hip_dev_canny (blocking)",
+                   else "canny_hip_dev_canny (asynchronous: K calls queued back to back, the timed region ends with a device "
+                             "synchronize)",
                    "sharding": "independent frames per GPU, no collective"},
         "host_to_host": h2h,
         "roofline": roofline,
@@ -457,6 +468,8 @@ def main():
         "hysteresis_sweeps": hyst_sweeps,
         "parity_checked": parity,
     }
+    if rehearse:
+        out["rehearsal"] = True
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(base_np, args.sigma, args.min_val, args.max_val, args.cpu_frames)
         out["vs_cpu_baseline"] = {"device_resident": round(value / out["cpu_baseline"]["value"], 1),

@@ -1,14 +1,16 @@
 // main.cpp -- the reference's command line (StevenChang5/Canny_Edge src/main.cpp:18-142) without
-// the webcam and the GUI:  ./Main sigma minVal maxVal [-c] [-s] [-i in.pgm] [-o dir] [-n WxH]
+// the webcam and the GUI:  ./Main sigma minVal maxVal [-c] [-s] [-i in.pgm|in.jpg] [-o dir] [-n WxH] [-b dir]
 //
 // Kept from the reference: the three positionals may appear anywhere relative to the flags
 // (src/main.cpp:29-46); exactly three are required, otherwise the usage text is printed and the
 // program exits with status 0 (:48-56); maxVal must exceed minVal and both must lie in [0,255]
 // (:63-76), again exiting 0 with the reference's messages; -s shows the steps, -c selects the GPU
 // entry point (cuda_canny) instead of canny().  In this build both run on the MI355X.
-// Replaced: VideoCapture(0) 640x480 (:78-115) -> a binary PGM given with -i, or a synthetic frame
-// of the webcam's size (-n overrides the size); imshow -> PGM files in the -o directory.
+// Replaced: VideoCapture(0) 640x480 (:78-115) -> a binary PGM or a baseline JPEG given with -i (the JPEG is read as
+// cv::imread(..., IMREAD_GRAYSCALE) reads it, include/canny_frames.h), or a synthetic frame of the webcam's size
+// (-n overrides the size); imshow -> PGM files in the -o directory.
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "canny_frames.h"
 #include "canny_hip.h"
 #include "utils.h"
 #include "cuda.h"
@@ -50,6 +53,37 @@ static bool read_pgm(const string &path, vector<unsigned char> &px, int &height,
     px.resize((size_t)width * height);
     f.read((char *)px.data(), (streamsize)px.size());
     return (size_t)f.gcount() == px.size();
+}
+
+// A frame file: binary PGM, or a JPEG (told by its first two bytes, not by its name).
+static bool read_frame(const string &path, vector<unsigned char> &px, int &height, int &width)
+{
+    ifstream f(path, ios::binary);
+    if (!f) return false;
+    unsigned char magic[2] = {0, 0};
+    f.read((char *)magic, 2);
+    if (f.gcount() == 2 && magic[0] == 0xFF && magic[1] == 0xD8) {
+        f.seekg(0, ios::end);
+        vector<unsigned char> file((size_t)f.tellg());
+        f.seekg(0);
+        f.read((char *)file.data(), (streamsize)file.size());
+        int st = canny_frames_jpeg_info(file.data(), file.size(), &height, &width);
+        if (!st) {
+            px.resize((size_t)width * height);
+            st = canny_frames_jpeg_decode_gray(file.data(), file.size(), px.data(), px.size(), &height, &width);
+        }
+        if (st) cout << "ERROR: " << path << ": " << canny_frames_last_error() << endl;
+        return st == 0;
+    }
+    f.close();
+    return read_pgm(path, px, height, width);
+}
+
+static bool is_frame_file(const std::filesystem::path &p)
+{
+    string ext = p.extension().string();
+    transform(ext.begin(), ext.end(), ext.begin(), [](unsigned char c) { return (char)tolower(c); });
+    return ext == ".pgm" || ext == ".jpg" || ext == ".jpeg";
 }
 
 // Deterministic test card: gray background, filled rectangles, a little noise (xorshift).
@@ -87,7 +121,7 @@ static bool write_pgm(const string &path, const unsigned char *px, int height, i
     return (bool)f;
 }
 
-// -b dir: every *.pgm of the directory (sorted by name, all of one size) goes through the stream-overlapped
+// -b dir: every *.pgm / *.jpg / *.jpeg of the directory (sorted by name, all of one size) goes through the stream-overlapped
 // batch entry point in one call; the 0/255 edge maps come back as bytes and are written as <name>_edges.pgm.
 // The reference has no such mode (it loops over webcam frames, src/main.cpp:120-137); SURVEY.md 8(f) item 1.
 static int run_batch(const string &dir, const string &outdir, float sigma, int minVal, int maxVal)
@@ -96,9 +130,9 @@ static int run_batch(const string &dir, const string &outdir, float sigma, int m
     vector<fs::path> files;
     error_code ec;
     for (const auto &e : fs::directory_iterator(dir, ec))
-        if (e.is_regular_file() && e.path().extension() == ".pgm") files.push_back(e.path());
+        if (e.is_regular_file() && is_frame_file(e.path())) files.push_back(e.path());
     if (ec || files.empty()) {
-        cout << "ERROR: no .pgm frames in " << dir << endl;
+        cout << "ERROR: no .pgm / .jpg frames in " << dir << endl;
         return -1;
     }
     sort(files.begin(), files.end());
@@ -106,7 +140,7 @@ static int run_batch(const string &dir, const string &outdir, float sigma, int m
     vector<unsigned char> frames, one;
     for (size_t i = 0; i < files.size(); i++) {
         int h = 0, w = 0;
-        if (!read_pgm(files[i].string(), one, h, w) || (i > 0 && (h != height || w != width))) {
+        if (!read_frame(files[i].string(), one, h, w) || (i > 0 && (h != height || w != width))) {
             cout << "ERROR: Failed to open " << files[i].string() << " (or its size differs from the first frame)" << endl;
             return -1;
         }
@@ -183,8 +217,8 @@ int main(int argc, char *argv[])
         fprintf(stderr, "   maxVal: The maximum threshold value used for hysteresis\n");
         fprintf(stderr, "           Must be in the range of [0,255]\n");
         fprintf(stderr, "   -c: use the GPU entry point (cuda_canny)   -s: write every step\n");
-        fprintf(stderr, "   -i in.pgm: input frame (binary PGM)   -n WxH: synthetic frame size   -o dir: output dir\n");
-        fprintf(stderr, "   -b dir: run every .pgm of dir as one batch, write <name>_edges.pgm\n");
+        fprintf(stderr, "   -i frame: input frame (binary PGM or baseline JPEG)   -n WxH: synthetic frame size   -o dir: output dir\n");
+        fprintf(stderr, "   -b dir: run every .pgm / .jpg of dir as one batch, write <name>_edges.pgm\n");
         exit(0);
     }
 
@@ -214,7 +248,7 @@ int main(int argc, char *argv[])
 
     vector<unsigned char> frame;
     if (!input.empty()) {
-        if (!read_pgm(input, frame, height, width)) {
+        if (!read_frame(input, frame, height, width)) {
             cout << "ERROR: Failed to open " << input << endl;
             return -1;
         }

@@ -35,6 +35,13 @@ def fixture_image():
 
 
 @pytest.fixture(scope="session")
+def luma_image():
+    """The same file's luminance plane as libjpeg returns it for JCS_GRAYSCALE -- what cv::imread(IMREAD_GRAYSCALE)
+    gives the reference's tests (tests/utils/test_utils.cpp:49); made by tests/golden/make_fixtures.py with PIL."""
+    return np.fromfile(os.path.join(GOLDEN, "test_luma_256x256.u8"), dtype=np.uint8).reshape(256, 256)
+
+
+@pytest.fixture(scope="session")
 def hip():
     """The product C-ABI binding; GPU tests fail loudly if it cannot be loaded."""
     from canny_edge_amd import capi

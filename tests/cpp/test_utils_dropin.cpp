@@ -16,6 +16,7 @@
 
 #include "utils.h"
 #include "cuda.h"
+#include "canny_frames.h"
 
 static int failures = 0, checks = 0;
 #define CHECK(cond)                                                                  \
@@ -197,6 +198,38 @@ int main(int argc, char **argv)
             delete[] gmag;
             delete[] gang;
             delete[] gnms;
+        }
+    }
+
+    // The same image tests the way the reference runs them: from the JPEG itself.  cv::imread(path, IMREAD_GRAYSCALE)
+    // (tests/utils/test_utils.cpp:49) becomes canny_frames_jpeg_decode_gray (include/canny_frames.h), which returns the
+    // same bytes (libjpeg's luminance plane).  Gaussian.IsNonzero / InRange -- :47-104, then the whole pipeline.
+    if (argc > 2) {
+        std::vector<unsigned char> file = load_fixture(argv[2]);
+        int height = 0, width = 0;
+        CHECK(canny_frames_jpeg_info(file.data(), file.size(), &height, &width) == CANNY_FRAMES_OK);
+        CHECK(height == 256 && width == 256);
+        std::vector<unsigned char> img((size_t)height * width);
+        CHECK(canny_frames_jpeg_decode_gray(file.data(), file.size(), img.data(), img.size(), &height, &width) ==
+              CANNY_FRAMES_OK);
+        if (height == 256 && width == 256) {
+            unsigned char *data = img.data();
+            short int *smoothed;
+            gaussian(data, 0.5, height, width, smoothed);
+            long sum = 0;
+            bool in_range = true;
+            for (int i = 0; i < height * width; i++) {
+                sum += smoothed[i];
+                in_range = in_range && smoothed[i] <= 255 && smoothed[i] >= 0;
+            }
+            CHECK(sum != 0);
+            CHECK(in_range);
+            delete[] smoothed;
+            short int *edges = cannyEdges(data, 1.0f, 50, 150, height, width);
+            long edge_pixels = 0;
+            for (int i = 0; i < height * width; i++) edge_pixels += edges[i] == EDGE;
+            CHECK(edge_pixels == 2445); // the oracle's count on this decode (tests/golden/oracle_stage_hashes.json)
+            delete[] edges;
         }
     }
 

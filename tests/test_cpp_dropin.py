@@ -24,6 +24,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 def _build():
     src = os.path.join(ROOT, "tests", "cpp", "test_utils_dropin.cpp")
     deps = [src, os.path.join(ROOT, "include", "utils.h"), os.path.join(ROOT, "include", "cuda.h"),
+            os.path.join(ROOT, "include", "canny_frames.h"),
             os.path.join(PKG, "libcanny_utils.so")]
     if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
         return
@@ -39,7 +40,8 @@ def test_reference_test_source_shape_compiles_against_dropin_headers():
 @pytest.mark.gpu
 def test_reference_vectors_through_cpp_dropin():
     _build()
-    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", "test_gray_256x256.u8")], capture_output=True,
+    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", "test_gray_256x256.u8"),
+                        os.path.join(ROOT, "tests", "golden", "test.jpg")], capture_output=True,
                        text=True, cwd=ROOT, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failures" in r.stdout
@@ -106,3 +108,45 @@ def test_cli_batch_directory(tmp_path):
     for name, img in frames.items():
         got = _read_pgm(dst / f"{name}_edges.pgm")
         assert np.array_equal(got, oracle.canny(img, 1.0, 40, 120).astype(np.uint8)), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["-c"]])
+def test_cli_reads_the_reference_jpeg(tmp_path, flags, luma_image, oracle_hashes):
+    """./Main on the reference's own tests/test.jpg: decoded as cv::imread(IMREAD_GRAYSCALE) decodes it
+    (include/canny_frames.h), the edge map equals the oracle's on the committed luminance plane."""
+    cmd = [os.path.join(PKG, "Main"), "1.0", "50", "150", "-i", os.path.join(ROOT, "tests", "golden", "test.jpg"),
+           "-o", str(tmp_path)] + flags
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = _read_pgm(tmp_path / "canny_edges.pgm")
+    assert np.array_equal(got, oracle.canny(luma_image, 1.0, 50, 150).astype(np.uint8))
+    assert int(np.count_nonzero(got)) == oracle_hashes["jpegluma256_s1.0_50_150"]["edge_pixels"]
+
+
+@pytest.mark.gpu
+def test_cli_batch_directory_mixes_jpeg_and_pgm(tmp_path, luma_image):
+    import shutil
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    dst.mkdir()
+    other = synth_frame(256, 256, 77)
+    shutil.copyfile(os.path.join(ROOT, "tests", "golden", "test.jpg"), src / "a_photo.JPG")
+    _write_pgm(src / "b_card.pgm", other)
+    (src / "notes.txt").write_text("not a frame")
+    r = subprocess.run([os.path.join(PKG, "Main"), "1.0", "50", "150", "-b", str(src), "-o", str(dst)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "2 frames of 256x256" in r.stdout
+    assert np.array_equal(_read_pgm(dst / "a_photo_edges.pgm"), oracle.canny(luma_image, 1.0, 50, 150).astype(np.uint8))
+    assert np.array_equal(_read_pgm(dst / "b_card_edges.pgm"), oracle.canny(other, 1.0, 50, 150).astype(np.uint8))
+
+
+def test_cli_reports_a_damaged_jpeg(tmp_path):
+    """No GPU needed: the frame is rejected before any context exists."""
+    data = open(os.path.join(ROOT, "tests", "golden", "test.jpg"), "rb").read()
+    (tmp_path / "cut.jpg").write_bytes(data[:5000])
+    r = subprocess.run([os.path.join(PKG, "Main"), "1.0", "50", "150", "-i", str(tmp_path / "cut.jpg")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+    assert "truncated or damaged" in r.stdout and "Failed to open" in r.stdout

@@ -131,10 +131,11 @@ def test_hysteresis_directed_quirk():
 
 
 # ---- committed regression pins of the oracle itself -------------------------------------------
-def test_oracle_stage_hashes(oracle_hashes, fixture_image):
+def test_oracle_stage_hashes(oracle_hashes, fixture_image, luma_image):
     inputs = {
         "fixture256_s0.5_50_150": fixture_image,
         "fixture256_s1.0_50_150": fixture_image,
+        "jpegluma256_s1.0_50_150": luma_image,
         "synth_97x131_seed7_s1.4_50_150": synth_frame(97, 131, 7),
         "synth_240x320_seed42_s2.0_30_90": synth_frame(240, 320, 42),
         "synth_64x64_seed3_s0.5_10_50": synth_frame(64, 64, 3),

@@ -293,7 +293,8 @@ def main():
     # ... and only every 4th step carries that pair: even an attached pair makes the dispatch wait for the stream to
     # drain (~0.04 ms per step it is on); `launches_timed` says how many launches the average is over.
     ctx.set_option("profile_stage_mask", 1 << capi.STAGE_SOBEL_NMS)
-    ctx.set_option("profile_sample_interval", max(1, min(4, args.steps // 3)))
+    sample_every = max(1, min(4, args.steps // 3))
+    ctx.set_option("profile_sample_interval", sample_every)
     ctx.profile_enable(True)
     ctx.profile_reset()
 
@@ -322,7 +323,8 @@ def main():
         stages[name] = {"ms_per_step": round(ms / max(1, args.steps), 4), "launch_groups": n,
                         "timed": "second pass, all stages bracketed by events"}
     stages["sobel_nms"] = {"ms_per_step": round(sn_ms_total / max(1, sn_launches), 4), "launch_groups": sn_launches,
-                           "timed": "inside the timed region, on every 4th step"}
+                           "timed": f"inside the timed region, on every {sample_every}th step" if sample_every > 1
+                           else "inside the timed region, on every step"}
     ctx.profile_enable(False)
     hyst_sweeps = ctx.last_hysteresis_iterations
 

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Tuple
 
 import numpy as np
@@ -461,15 +462,17 @@ def cpulist_count(text: str) -> int:
     return load().canny_hip_selftest_cpulist_count(text.encode())
 
 
-# ---- the reference's stage names (src/utils.h:8-22) on a process-wide default context -------------
-_default: Optional[Context] = None
+# ---- the reference's stage names (src/utils.h:8-22) on a default context per calling thread --------
+# (the reference's functions are re-entrant; a context serves one thread at a time, so -- like the C++ shim's
+# thread_local context, csrc/utils_shim.cpp -- every thread that uses these names gets a context of its own)
+_default = threading.local()
 
 
 def default_context() -> Context:
-    global _default
-    if _default is None:
-        _default = Context(int(os.environ.get("CANNY_HIP_DEVICE", "0")))
-    return _default
+    ctx = getattr(_default, "ctx", None)
+    if ctx is None:
+        ctx = _default.ctx = Context(int(os.environ.get("CANNY_HIP_DEVICE", "0")))
+    return ctx
 
 
 def createGaussianKernel(sigma: float) -> np.ndarray:

@@ -1,5 +1,5 @@
 // main.cpp -- the reference's command line (StevenChang5/Canny_Edge src/main.cpp:18-142) without
-// the webcam and the GUI:  ./Main sigma minVal maxVal [-c] [-s] [-i in.pgm|in.jpg] [-o dir] [-n WxH] [-b dir]
+// the webcam and the GUI:  ./Main sigma minVal maxVal [-c] [-s] [-i in.pgm|in.jpg] [-o dir] [-p] [-n WxH] [-b dir]
 //
 // Kept from the reference: the three positionals may appear anywhere relative to the flags
 // (src/main.cpp:29-46); exactly three are required, otherwise the usage text is printed and the
@@ -8,7 +8,7 @@
 // entry point (cuda_canny) instead of canny().  In this build both run on the MI355X.
 // Replaced: VideoCapture(0) 640x480 (:78-115) -> a binary PGM or a baseline JPEG given with -i (the JPEG is read as
 // cv::imread(..., IMREAD_GRAYSCALE) reads it, include/canny_frames.h), or a synthetic frame of the webcam's size
-// (-n overrides the size); imshow -> PGM files in the -o directory.
+// (-n overrides the size); imshow -> PGM (or, with -p, PNG) files in the -o directory.
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -112,13 +112,11 @@ static void synthetic_frame(vector<unsigned char> &px, int height, int width)
     }
 }
 
-static bool write_pgm(const string &path, const unsigned char *px, int height, int width)
+static bool png_output = false; // -p: results as PNG instead of PGM
+
+static bool write_frame(const string &path, const unsigned char *px, int height, int width)
 {
-    ofstream f(path, ios::binary);
-    if (!f) return false;
-    f << "P5\n" << width << " " << height << "\n255\n";
-    f.write((const char *)px, (streamsize)((size_t)width * height));
-    return (bool)f;
+    return canny_frames_write_gray(path.c_str(), px, height, width) == CANNY_FRAMES_OK;
 }
 
 // -b dir: every *.pgm / *.jpg / *.jpeg of the directory (sorted by name, all of one size) goes through the stream-overlapped
@@ -165,8 +163,8 @@ static int run_batch(const string &dir, const string &outdir, float sigma, int m
     canny_hip_ctx_destroy(ctx);
     const fs::path out = outdir.empty() ? fs::path(dir) : fs::path(outdir);
     for (size_t i = 0; i < files.size(); i++) {
-        const fs::path dst = out / (files[i].stem().string() + "_edges.pgm");
-        if (!write_pgm(dst.string(), edges.data() + i * frame_px, height, width)) {
+        const fs::path dst = out / (files[i].stem().string() + (png_output ? "_edges.png" : "_edges.pgm"));
+        if (!write_frame(dst.string(), edges.data() + i * frame_px, height, width)) {
             cout << "ERROR: Failed to write " << dst.string() << endl;
             return -1;
         }
@@ -193,6 +191,8 @@ int main(int argc, char *argv[])
             use_gpu_entry = true;
         } else if (arg == "-s") {
             show_steps = true;
+        } else if (arg == "-p") {
+            png_output = true;
         } else if (arg == "-i" && i + 1 < argc) {
             input = argv[++i];
         } else if (arg == "-o" && i + 1 < argc) {
@@ -218,6 +218,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "           Must be in the range of [0,255]\n");
         fprintf(stderr, "   -c: use the GPU entry point (cuda_canny)   -s: write every step\n");
         fprintf(stderr, "   -i frame: input frame (binary PGM or baseline JPEG)   -n WxH: synthetic frame size   -o dir: output dir\n");
+        fprintf(stderr, "   -p: write PNG files instead of PGM\n");
         fprintf(stderr, "   -b dir: run every .pgm / .jpg of dir as one batch, write <name>_edges.pgm\n");
         exit(0);
     }
@@ -256,6 +257,7 @@ int main(int argc, char *argv[])
         synthetic_frame(frame, height, width);
     }
     if (!outdir.empty()) setenv("CANNY_OUTPUT_DIR", outdir.c_str(), 1);
+    if (png_output) setenv("CANNY_OUTPUT_FORMAT", "png", 1);
 
     try {
         if (use_gpu_entry)

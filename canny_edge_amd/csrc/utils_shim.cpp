@@ -5,6 +5,7 @@
 #include "utils.h"
 #include "cuda.h"
 
+#include "canny_frames.h"
 #include "canny_hip.h"
 
 #include <chrono>
@@ -58,16 +59,13 @@ std::string out_dir()
     return env && *env ? std::string(env) : std::string(".");
 }
 
+// CANNY_OUTPUT_FORMAT=png turns the ".pgm" of every output name into ".png" (Main -p sets it).
 void write_pgm(const std::string &name, const unsigned char *px, int height, int width)
 {
     std::string path = out_dir() + "/" + name;
-    std::ofstream f(path, std::ios::binary);
-    if (!f) {
-        std::cerr << "WARNING: cannot write " << path << "\n";
-        return;
-    }
-    f << "P5\n" << width << " " << height << "\n255\n";
-    f.write((const char *)px, (std::streamsize)count(height, width));
+    const char *fmt = std::getenv("CANNY_OUTPUT_FORMAT");
+    if (fmt && std::string(fmt) == "png" && path.size() > 4) path.replace(path.size() - 4, 4, ".png");
+    if (canny_frames_write_gray(path.c_str(), px, height, width)) std::cerr << "WARNING: cannot write " << path << "\n";
 }
 
 // The reference shows each plane through cv::normalize(src, dst, 0, 255, NORM_MINMAX) followed by

@@ -35,7 +35,13 @@ int canny_frames_jpeg_info(const void *data, size_t bytes, int *height, int *wid
 int canny_frames_jpeg_decode_gray(const void *data, size_t bytes, unsigned char *out, size_t out_bytes, int *height,
                                   int *width);
 
-/* Text of the calling thread's last failure ("" if none). */
+/* Frame sink: writes height*width gray bytes as a PNG when `path` ends in ".png" (8-bit gray, stored -- not compressed --
+ * deflate blocks), as a binary PGM otherwise.  What stands in for the reference's cv::imshow windows
+ * (src/utils.cpp:440-486) in a headless build.  CANNY_FRAMES_ERR_ARG: bad argument or the file cannot be created;
+ * CANNY_FRAMES_ERR_FORMAT: the write failed part-way. */
+int canny_frames_write_gray(const char *path, const unsigned char *px, int height, int width);
+
+/* Text of the calling thread's last JPEG failure ("" if none). */
 const char *canny_frames_last_error(void);
 
 #ifdef __cplusplus

@@ -150,3 +150,19 @@ def test_cli_reports_a_damaged_jpeg(tmp_path):
                        capture_output=True, text=True, timeout=60)
     assert r.returncode != 0
     assert "truncated or damaged" in r.stdout and "Failed to open" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_png_output(tmp_path):
+    """-p: every output of the run as PNG (8-bit gray), same pixels as the PGM run."""
+    Image = pytest.importorskip("PIL.Image")
+    img = synth_frame(200, 333, 9)
+    _write_pgm(tmp_path / "frame.pgm", img)
+    r = subprocess.run([os.path.join(PKG, "Main"), "1.4", "50", "150", "-s", "-p", "-i", str(tmp_path / "frame.pgm"),
+                        "-o", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = oracle.canny(img, 1.4, 50, 150)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "canny_edges.png")), want.astype(np.uint8))
+    for name in ("canny_step1_gaussian.png", "canny_step2_gradient.png", "canny_step3_nonmaximal.png"):
+        assert Image.open(tmp_path / name).size == (333, 200)
+    assert not list(tmp_path.glob("canny_*.pgm"))

@@ -1,4 +1,4 @@
-"""The JPEG frame source (include/canny_frames.h, canny_edge_amd/csrc/jpeg_gray.cpp) -- CPU only.
+"""The JPEG frame source and the PGM/PNG sink (include/canny_frames.h, csrc/jpeg_gray.cpp, csrc/png_gray.cpp) -- CPU only.
 
 The reference's tests read their frame with cv::imread("test.jpg", IMREAD_GRAYSCALE) (tests/utils/test_utils.cpp:49):
 libjpeg's luminance plane.  The decoder must return exactly those bytes:
@@ -65,7 +65,8 @@ def pil_luma(data: bytes):
 def test_header_symbols_exported():
     header = open(os.path.join(ROOT, "include", "canny_frames.h")).read()
     declared = sorted(set(re.findall(r"\b(canny_frames_[a-z0-9_]+)\s*\(", header)))
-    assert declared == ["canny_frames_jpeg_decode_gray", "canny_frames_jpeg_info", "canny_frames_last_error"]
+    assert declared == ["canny_frames_jpeg_decode_gray", "canny_frames_jpeg_info", "canny_frames_last_error",
+                        "canny_frames_write_gray"]
     L = ctypes.CDLL(LIB)
     assert all(hasattr(L, name) for name in declared)
 
@@ -349,3 +350,39 @@ def test_python_frame_source(tmp_path, luma_image):
     with pytest.raises(frames.FrameError) as ei:
         frames.jpeg_decode_gray(b"\xff\xd8\xff\xd9")
     assert ei.value.status == ERR_FORMAT
+
+
+# ---- the frame sink ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 5), (256, 256), (300, 70000 // 300 + 7), (1100, 1000)])
+def test_png_and_pgm_sink(tmp_path, h, w):
+    """canny_frames_write_gray: the PNG is read back with PIL and, independently, taken apart by hand (chunk CRCs, zlib
+    stream of stored blocks); sizes straddle the 65535-byte block and the 1 MiB IDAT limits."""
+    import zlib
+    L = ctypes.CDLL(LIB)
+    L.canny_frames_write_gray.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    img = np.random.default_rng(h * w).integers(0, 256, (h, w), dtype=np.uint8)
+    png, pgm = tmp_path / "frame.PNG", tmp_path / "frame.pgm"
+    assert L.canny_frames_write_gray(str(png).encode(), img.ctypes.data, h, w) == OK
+    assert L.canny_frames_write_gray(str(pgm).encode(), img.ctypes.data, h, w) == OK
+    assert pgm.read_bytes() == b"P5\n%d %d\n255\n" % (w, h) + img.tobytes()
+    data = png.read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, kinds = 8, b"", []
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body)
+        kinds.append(kind)
+        if kind == b"IHDR":
+            assert body == struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)
+        if kind == b"IDAT":
+            assert n <= 1 << 20
+            idat += body
+        pos += 12 + n
+    assert kinds[0] == b"IHDR" and kinds[-1] == b"IEND" and set(kinds[1:-1]) == {b"IDAT"}
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w + 1)
+    assert not raw[:, 0].any() and np.array_equal(raw[:, 1:], img)
+    Image = pytest.importorskip("PIL.Image")
+    back = Image.open(str(png))
+    assert back.mode == "L" and np.array_equal(np.asarray(back), img)
+    assert L.canny_frames_write_gray(str(tmp_path / "no_such_dir" / "x.png").encode(), img.ctypes.data, h, w) == ERR_ARG

@@ -108,37 +108,40 @@ def host_to_host(ctx, np, base_np, args, rank, world, sync_max, check):
     px = n * H * W
     res = {"frames_per_gpu": n, "height": H, "width": W, "sigma": args.sigma, "reps": args.h2h_reps,
            "pcie_peak_GBps_per_direction": PCIE_PEAK_GBS,
-           "what": "canny_hip_canny_batch / _u8 on pinned host buffers: 3-stream chunk pipeline "
-                   "(upload | kernels | download), wall time of the median of --h2h-reps calls, MAX over ranks"}
+           "what": "canny_hip_canny_batch / _u8 / _bits on pinned host buffers: 3-stream chunk pipeline "
+                   "(upload | kernels | download), wall time of the median of --h2h-reps calls, MAX over ranks; "
+                   "s16 = the reference's short maps, u8 = the same 0/255 as bytes, bits = 1 bit per pixel"}
     if True:  # the bench's own context: its stream is idle here, and every extra stream costs a hardware queue
         src = ctx.pinned_array((n, H, W), np.uint8)
         for i in range(n):
             src[i] = base_np[i % len(base_np)]
-        outs = {"s16": ctx.pinned_array((n, H, W), np.int16), "u8": ctx.pinned_array((n, H, W), np.uint8)}
+        outs = {"s16": ctx.pinned_array((n, H, W), np.int16), "u8": ctx.pinned_array((n, H, W), np.uint8),
+                "bits": ctx.pinned_array((n, H, (W + 7) // 8), np.uint8)}
         for name, out in outs.items():
-            u8 = name == "u8"
+            u8, bits = name == "u8", name == "bits"
             out[...] = 1
             for _ in range(2):  # builds pipelines and staging; lets the link clocks settle after the compute phase
-                ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8)
+                ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8, bits=bits)
             sync_max(0.0)
             calls = []
             for _ in range(args.h2h_reps):  # every call timed; the figure is the MEDIAN call (MAX over ranks)
                 t0 = time.perf_counter()
-                ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8)
+                ctx.canny_batch(src, args.sigma, args.min_val, args.max_val, out=out, u8=u8, bits=bits)
                 calls.append(time.perf_counter() - t0)
             t = sync_max(sorted(calls)[len(calls) // 2])
-            h2d, d2h = px / t / 1e9, px * out.itemsize / t / 1e9
+            out_bytes_per_px = out.nbytes / px
+            h2d, d2h = px / t / 1e9, out.nbytes / t / 1e9
             res[name] = {"value": round(px * world / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_batch": round(t * 1e3, 3),
                          "ms_per_call": [round(c * 1e3, 2) for c in calls],
                          "h2d_GBps_per_gpu": round(h2d, 2), "d2h_GBps_per_gpu": round(d2h, 2),
                          "link_frac": round(max(h2d, d2h) / PCIE_PEAK_GBS, 4),
-                         "bytes_over_link_per_px": 1 + out.itemsize}
+                         "bytes_over_link_per_px": round(1 + out_bytes_per_px, 4)}
             # one frame at a time (latency): pinned in, pinned out
             one_in, one_out = src[:1], out[:1]
-            ctx.canny_batch(one_in, args.sigma, args.min_val, args.max_val, out=one_out, u8=u8)
+            ctx.canny_batch(one_in, args.sigma, args.min_val, args.max_val, out=one_out, u8=u8, bits=bits)
             t0 = time.perf_counter()
             for _ in range(10):
-                ctx.canny_batch(one_in, args.sigma, args.min_val, args.max_val, out=one_out, u8=u8)
+                ctx.canny_batch(one_in, args.sigma, args.min_val, args.max_val, out=one_out, u8=u8, bits=bits)
             res[name]["single_frame_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
         if check:
             import oracle
@@ -146,7 +149,8 @@ def host_to_host(ctx, np, base_np, args, rank, world, sync_max, check):
             for i in (0, n - 1):
                 want = oracle.canny(base_np[i % len(base_np)], args.sigma, args.min_val, args.max_val)
                 ok = ok and bool(np.array_equal(outs["s16"][i], want)) and \
-                    bool(np.array_equal(outs["u8"][i], want.astype(np.uint8)))
+                    bool(np.array_equal(outs["u8"][i], want.astype(np.uint8))) and \
+                    bool(np.array_equal(outs["bits"][i], np.packbits(want != 0, axis=-1)))
             res["parity_checked"] = ok
             if not ok:
                 raise SystemExit("bench.py: host-to-host edge maps differ from the oracle -- refusing to report")

@@ -47,6 +47,7 @@ EXPORTS = (
     "canny_hip_selftest_div_fma_table", "canny_hip_canny_multi_gpu_u8", "canny_hip_multi_gpu_set_option",
     "canny_hip_multi_gpu_release", "canny_hip_device_local_cpus", "canny_hip_selftest_cpulist_count",
     "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in", "canny_hip_host_register", "canny_hip_host_unregister",
+    "canny_hip_canny_batch_bits", "canny_hip_canny_multi_gpu_bits", "canny_hip_dev_canny_bits",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -103,6 +104,9 @@ def load() -> C.CDLL:
         "canny_hip_canny_batch": ([p, p, i, f, i, i, i, i, p], i),
         "canny_hip_canny_batch_u8": ([p, p, i, f, i, i, i, i, p], i),
         "canny_hip_dev_canny_u8": ([p, p, f, i, i, i, i, i, p], i),
+        "canny_hip_dev_canny_bits": ([p, p, f, i, i, i, i, i, p], i),
+        "canny_hip_canny_batch_bits": ([p, p, i, f, i, i, i, i, p], i),
+        "canny_hip_canny_multi_gpu_bits": ([p, i, f, i, i, i, i, p, i], i),
         "canny_hip_canny_multi_gpu": ([p, i, f, i, i, i, i, p, i], i),
         "canny_hip_canny_multi_gpu_u8": ([p, i, f, i, i, i, i, p, i], i),
         "canny_hip_multi_gpu_set_option": ([C.c_char_p, i], i),
@@ -332,18 +336,21 @@ class Context:
         self._check(self._L.canny_hip_host_unregister(self._h, _hp(a)), "host_unregister")
 
     def canny_batch(self, imgs, sigma: float, min_val: int, max_val: int, out: Optional[np.ndarray] = None,
-                    u8: bool = False) -> np.ndarray:
+                    u8: bool = False, bits: bool = False) -> np.ndarray:
         """Host frames in, host edge maps out, transfers overlapped with the kernels.  u8=True returns the maps as
-        uint8 (0 / 255) instead of the reference's int16: a third less PCIe traffic."""
+        uint8 (0 / 255) instead of the reference's int16: a third less PCIe traffic.  bits=True returns bit maps,
+        uint8 [n_frames, H, (W + 7) // 8], rows packed MSB-first like numpy.packbits (see unpack_bits())."""
         a = np.ascontiguousarray(imgs, dtype=np.uint8)
         if a.ndim != 3:
             raise ValueError("expected uint8 [n_frames, H, W]")
-        dtype = np.uint8 if u8 else np.int16
+        dtype = np.uint8 if (u8 or bits) else np.int16
+        shape = bits_shape(a.shape) if bits else a.shape
         if out is None:
-            out = np.empty(a.shape, dtype)
-        elif out.shape != a.shape or out.dtype != dtype or not out.flags["C_CONTIGUOUS"]:
-            raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of the input's shape")
-        fn = self._L.canny_hip_canny_batch_u8 if u8 else self._L.canny_hip_canny_batch
+            out = np.empty(shape, dtype)
+        elif out.shape != shape or out.dtype != dtype or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of shape {shape}")
+        fn = self._L.canny_hip_canny_batch_bits if bits else \
+            (self._L.canny_hip_canny_batch_u8 if u8 else self._L.canny_hip_canny_batch)
         self._check(fn(self._h, _hp(a), a.shape[0], sigma, min_val, max_val, a.shape[1], a.shape[2], _hp(out)),
                     "canny_batch")
         return out
@@ -417,24 +424,41 @@ class Context:
     def dev_canny_stream_flush(self):
         self._check(self._L.canny_hip_dev_canny_stream_flush(self._h), "dev_canny_stream_flush")
 
+    def dev_canny_bits(self, d_img: int, sigma: float, min_val: int, max_val: int, h: int, w: int, n: int, d_bits: int):
+        self._check(self._L.canny_hip_dev_canny_bits(self._h, C.c_void_p(d_img), sigma, min_val, max_val, h, w, n,
+                                                     C.c_void_p(d_bits)), "dev_canny_bits")
+
     def dev_canny_u8(self, d_img: int, sigma: float, min_val: int, max_val: int, h: int, w: int, n: int, d_edges: int):
         self._check(self._L.canny_hip_dev_canny_u8(self._h, C.c_void_p(d_img), sigma, min_val, max_val, h, w, n,
                                                    C.c_void_p(d_edges)), "dev_canny_u8")
 
 
+def bits_shape(frames_shape) -> Tuple[int, int, int]:
+    """Shape of the bit maps of [n_frames, H, W] frames: every row padded to whole bytes."""
+    n, h, w = frames_shape
+    return (n, h, (w + 7) // 8)
+
+
+def unpack_bits(bits: np.ndarray, width: int) -> np.ndarray:
+    """Bit maps [n_frames, H, (W + 7) // 8] -> the reference's int16 edge maps (0 / 255)."""
+    return np.unpackbits(bits, axis=-1)[..., :width].astype(np.int16) * 255
+
+
 def canny_multi_gpu(imgs, sigma: float, min_val: int, max_val: int, n_devices: int = 0, u8: bool = False,
-                    out: Optional[np.ndarray] = None) -> np.ndarray:
+                    out: Optional[np.ndarray] = None, bits: bool = False) -> np.ndarray:
     """Shard [n_frames, H, W] by contiguous ranges over the node's GPUs (one host thread per GPU, each running
     the batch pipeline; per-device contexts are cached until multi_gpu_release())."""
     a = np.ascontiguousarray(imgs, dtype=np.uint8)
     if a.ndim != 3:
         raise ValueError("expected uint8 [n_frames, H, W]")
-    dtype = np.uint8 if u8 else np.int16
+    dtype = np.uint8 if (u8 or bits) else np.int16
+    shape = bits_shape(a.shape) if bits else a.shape
     if out is None:
-        out = np.empty(a.shape, dtype)
-    elif out.shape != a.shape or out.dtype != dtype or not out.flags["C_CONTIGUOUS"]:
-        raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of the input's shape")
-    fn = load().canny_hip_canny_multi_gpu_u8 if u8 else load().canny_hip_canny_multi_gpu
+        out = np.empty(shape, dtype)
+    elif out.shape != shape or out.dtype != dtype or not out.flags["C_CONTIGUOUS"]:
+        raise ValueError(f"out must be a C-contiguous {np.dtype(dtype).name} array of shape {shape}")
+    fn = load().canny_hip_canny_multi_gpu_bits if bits else \
+        (load().canny_hip_canny_multi_gpu_u8 if u8 else load().canny_hip_canny_multi_gpu)
     st = fn(_hp(a), a.shape[0], sigma, min_val, max_val, a.shape[1], a.shape[2], _hp(out), n_devices)
     if st:
         raise CannyHipError(st, "canny_multi_gpu")

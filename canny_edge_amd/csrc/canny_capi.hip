@@ -1221,9 +1221,17 @@ int canny_hip_shard_range(int n_frames, int rank, int world, int *begin, int *en
 //   pinned caller buffers (canny_hip_host_alloc, hipHostMalloc, hipHostRegister): DMA'd in place, one pipeline;
 //   pageable caller buffers: staged through the slot's pinned buffers by the pipeline's own thread (memcpy), so
 //   several pipelines run side by side to get enough copy bandwidth.
-// out_u8: `edges` is an unsigned char plane per frame (0 / 255) instead of a short plane.
+// What a batch call returns per frame: the reference's short plane (0 / 255), the same as bytes, or one bit per pixel
+// (rows MSB-first, padded to whole bytes -- launch_edges_to_bits).
+enum MapFormat { kMapS16 = 0, kMapU8 = 1, kMapBits = 2 };
+static size_t map_frame_bytes(MapFormat fmt, int height, int width)
+{
+    if (fmt == kMapBits) return (size_t)height * (size_t)((width + 7) / 8);
+    return npx(height, width, 1) * (fmt == kMapU8 ? 1 : sizeof(short));
+}
+
 static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
-                            int max_val, int height, int width, void *edges, bool out_u8)
+                            int max_val, int height, int width, void *edges, MapFormat fmt)
 {
     using Pipe = canny_hip_ctx::BatchPipe;
     int rc = bind(ctx);
@@ -1272,7 +1280,7 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
     if (three_streams)
         for (int i = 0; i < n_workers; i++)
             if ((rc = ensure_copy_streams(ctx, *ctx->batch_pool[i]))) return rc;
-    const size_t out_elem = out_u8 ? 1 : sizeof(short);
+    const size_t out_frame = map_frame_bytes(fmt, height, width); // bytes of one frame's map as the caller gets it
 
     auto worker = [&](int wid) {
         Pipe &P = *ctx->batch_pool[wid];
@@ -1286,7 +1294,7 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             return;
         }
         const int my_chunks = (n_chunks - wid + n_workers - 1) / n_workers;
-        const size_t in_bytes = frame_px * chunk, out_bytes = frame_px * chunk * out_elem;
+        const size_t in_bytes = frame_px * chunk, out_bytes = out_frame * chunk;
         hipError_t e = hipSuccess;
         constexpr int n_slots = Pipe::kSlots;
         for (int k = 0; k < std::min(my_chunks, n_slots) && e == hipSuccess; k++) {
@@ -1298,7 +1306,7 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             if (e == hipSuccess && !out_pinned) e = S.pin_out.ensure(out_bytes, device);
             if (e == hipSuccess) e = S.d_in.ensure(in_bytes);
             if (e == hipSuccess) e = S.d_out.ensure(frame_px * chunk * sizeof(short));
-            if (e == hipSuccess && out_u8) e = S.d_out8.ensure(out_bytes);
+            if (e == hipSuccess && fmt != kMapS16) e = S.d_out8.ensure(out_bytes);
         }
         if (e != hipSuccess) {
             st = fail(sub, e, "batch staging allocation");
@@ -1356,10 +1364,12 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
                            (short *)S.d_out.p);
             if (st) break;
             const void *d_res = S.d_out.p;
-            if (out_u8) { // narrow on the device: the D2H copy is what this variant is for
-                if ((e = launch_edges_to_u8((const int16_t *)S.d_out.p, (uint8_t *)S.d_out8.p, frame_px * nf,
-                                            sub->stream)) != hipSuccess)
-                    break;
+            if (fmt != kMapS16) { // narrow on the device: the D2H copy is what these variants are for
+                e = fmt == kMapU8 ? launch_edges_to_u8((const int16_t *)S.d_out.p, (uint8_t *)S.d_out8.p, frame_px * nf,
+                                                       sub->stream)
+                                  : launch_edges_to_bits((const int16_t *)S.d_out.p, (uint8_t *)S.d_out8.p, height, width,
+                                                         nf, sub->stream);
+                if (e != hipSuccess) break;
                 d_res = S.d_out8.p;
             }
             if ((e = hipEventRecord(S.ev_comp, sub->stream)) != hipSuccess) break;
@@ -1373,8 +1383,8 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             if ((e = hipEventSynchronize(S.ev_comp)) != hipSuccess) break;
             // download of chunk j (pin_out of this slot was retired kSlots - 1 iterations ago)
             where = "batch D2H";
-            unsigned char *dst = (unsigned char *)edges + (size_t)f0 * frame_px * out_elem;
-            const size_t bytes = frame_px * nf * out_elem;
+            unsigned char *dst = (unsigned char *)edges + (size_t)f0 * out_frame;
+            const size_t bytes = out_frame * nf;
             if ((e = hipStreamWaitEvent(s_d2h, S.ev_comp, 0)) != hipSuccess) break;
             if ((e = hipMemcpyAsync(out_pinned ? (void *)dst : S.pin_out.p, d_res, bytes, hipMemcpyDeviceToHost,
                                     s_d2h)) != hipSuccess)
@@ -1411,13 +1421,19 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
 int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
                           int max_val, int height, int width, short *edges)
 {
-    return canny_batch_impl(ctx, imgs, n_frames, sigma, min_val, max_val, height, width, edges, false);
+    return canny_batch_impl(ctx, imgs, n_frames, sigma, min_val, max_val, height, width, edges, kMapS16);
 }
 
 int canny_hip_canny_batch_u8(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
                              int max_val, int height, int width, unsigned char *edges)
 {
-    return canny_batch_impl(ctx, imgs, n_frames, sigma, min_val, max_val, height, width, edges, true);
+    return canny_batch_impl(ctx, imgs, n_frames, sigma, min_val, max_val, height, width, edges, kMapU8);
+}
+
+int canny_hip_canny_batch_bits(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                               int max_val, int height, int width, unsigned char *bits)
+{
+    return canny_batch_impl(ctx, imgs, n_frames, sigma, min_val, max_val, height, width, bits, kMapBits);
 }
 
 // ---- multi-GPU sharder (BASELINE config 5) -----------------------------------------------------------
@@ -1437,9 +1453,9 @@ MultiGpuState g_mgpu;
 } // namespace
 
 static int multi_gpu_impl(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val, int height,
-                          int width, void *edges, int n_devices, bool out_u8)
+                          int width, void *edges, int n_devices, MapFormat fmt)
 {
-    if (!imgs || !edges || n_frames < 1) return CANNY_HIP_ERR_INVALID;
+    if (!imgs || !edges || n_frames < 1 || height < 1 || width < 1) return CANNY_HIP_ERR_INVALID;
     int avail = 0;
     int rc = canny_hip_device_count(&avail);
     if (rc) return rc;
@@ -1450,7 +1466,7 @@ static int multi_gpu_impl(const unsigned char *imgs, int n_frames, float sigma, 
     if (n_devices > 64) return CANNY_HIP_ERR_INVALID;
     const int n_shards = n_devices;
     const size_t frame_px = npx(height, width, 1);
-    const size_t out_elem = out_u8 ? 1 : sizeof(short);
+    const size_t out_frame = map_frame_bytes(fmt, height, width);
     // contexts are created here, on the caller's thread, and kept for the next call
     while ((int)g_mgpu.shard_ctx.size() < n_shards) {
         const int shard = (int)g_mgpu.shard_ctx.size();
@@ -1478,7 +1494,7 @@ static int multi_gpu_impl(const unsigned char *imgs, int n_frames, float sigma, 
             if (own_thread || restore) (void)sched_setaffinity(0, sizeof local, &local); // best effort
         }
         status[shard] = canny_batch_impl(ctx, imgs + (size_t)b * frame_px, e - b, sigma, min_val, max_val, height,
-                                         width, (unsigned char *)edges + (size_t)b * frame_px * out_elem, out_u8);
+                                         width, (unsigned char *)edges + (size_t)b * out_frame, fmt);
         if (restore) (void)sched_setaffinity(0, sizeof saved, &saved);
     };
     std::vector<std::thread> threads;
@@ -1493,13 +1509,19 @@ static int multi_gpu_impl(const unsigned char *imgs, int n_frames, float sigma, 
 int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
                               int height, int width, short *edges, int n_devices)
 {
-    return multi_gpu_impl(imgs, n_frames, sigma, min_val, max_val, height, width, edges, n_devices, false);
+    return multi_gpu_impl(imgs, n_frames, sigma, min_val, max_val, height, width, edges, n_devices, kMapS16);
 }
 
 int canny_hip_canny_multi_gpu_u8(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
                                  int height, int width, unsigned char *edges, int n_devices)
 {
-    return multi_gpu_impl(imgs, n_frames, sigma, min_val, max_val, height, width, edges, n_devices, true);
+    return multi_gpu_impl(imgs, n_frames, sigma, min_val, max_val, height, width, edges, n_devices, kMapU8);
+}
+
+int canny_hip_canny_multi_gpu_bits(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
+                                   int height, int width, unsigned char *bits, int n_devices)
+{
+    return multi_gpu_impl(imgs, n_frames, sigma, min_val, max_val, height, width, bits, n_devices, kMapBits);
 }
 
 int canny_hip_multi_gpu_set_option(const char *name, int value)
@@ -1694,6 +1716,21 @@ int canny_hip_dev_canny_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float
     if ((rc = dev_canny(ctx, d_img, sigma, min_val, max_val, height, width, n_frames, (short *)ctx->edges16.p)))
         return rc;
     HIP_TRY(ctx, launch_edges_to_u8((const int16_t *)ctx->edges16.p, d_edges, n, ctx->stream));
+    return CANNY_HIP_OK;
+}
+
+int canny_hip_dev_canny_bits(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
+                             int height, int width, int n_frames, unsigned char *d_bits)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_img || !d_bits) return CANNY_HIP_ERR_INVALID;
+    if ((rc = check_dims(height, width, n_frames))) return rc;
+    const size_t n = npx(height, width, n_frames);
+    HIP_TRY(ctx, ctx->edges16.ensure(n * sizeof(short)));
+    if ((rc = dev_canny(ctx, d_img, sigma, min_val, max_val, height, width, n_frames, (short *)ctx->edges16.p)))
+        return rc;
+    HIP_TRY(ctx, launch_edges_to_bits((const int16_t *)ctx->edges16.p, d_bits, height, width, n_frames, ctx->stream));
     return CANNY_HIP_OK;
 }
 

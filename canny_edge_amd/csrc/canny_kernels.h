@@ -140,6 +140,9 @@ hipError_t launch_hyst_tail(uint64_t *strong, const uint64_t *conn, unsigned *sc
                             int edge_value = 0);
 // s16 edge map (0 / 255) -> u8, n pixels.
 hipError_t launch_edges_to_u8(const int16_t *edges, uint8_t *out, size_t n, hipStream_t stream);
+// s16 edge map -> packed bit map (1 = pixel != 0), rows MSB-first and padded to bytes: [n][height][(width + 7) / 8]
+hipError_t launch_edges_to_bits(const int16_t *edges, uint8_t *bits, int height, int width, int n_frames,
+                                hipStream_t stream);
 // Copies flags[0..1] (last_change, domain) to host_flags_dev[0..1] and then stores seq to host_flags_dev[2]
 // (system-scope release); host_flags_dev is the device view of pinned, mapped host memory.
 hipError_t launch_hyst_publish(const unsigned *flags, unsigned *host_flags_dev, unsigned seq, hipStream_t stream);

@@ -966,6 +966,46 @@ hipError_t launch_edges_to_u8(const int16_t *edges, uint8_t *out, size_t n, hipS
     return hipGetLastError();
 }
 
+// s16 edge map -> 1 bit per pixel (pixel != 0), rows packed MSB-first (pixel 0 of a row is bit 7 of the row's byte 0,
+// as in PBM "P4" and numpy.packbits), every row padded to whole bytes: [n_frames][height][(width + 7) / 8] bytes.
+// One byte -- 8 pixels, one 16-byte load where the row pitch allows it -- per thread and step.
+__global__ __launch_bounds__(256) void edges_to_bits_kernel(const int16_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                            int width, int row_bytes, size_t n_bytes, int vec_ok)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_bytes; b += stride) {
+        const size_t row = b / (size_t)row_bytes;
+        const int xb = (int)(b - row * (size_t)row_bytes);
+        const int16_t *px = in + row * (size_t)width + (size_t)xb * 8;
+        unsigned byte = 0;
+        if (vec_ok) { // width % 8 == 0 and a 16-byte aligned plane: every group of 8 pixels is one aligned uint4
+            const uint4 v = *reinterpret_cast<const uint4 *>(px);
+            const unsigned d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                byte |= (((d[k] & 0xffffu) != 0 ? 2u : 0u) | ((d[k] >> 16) != 0 ? 1u : 0u)) << (6 - 2 * k);
+        } else {
+            const int left = width - xb * 8; // pixels of this row from px on
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < left && px[k] != 0) byte |= 0x80u >> k;
+        }
+        out[b] = (uint8_t)byte;
+    }
+}
+
+hipError_t launch_edges_to_bits(const int16_t *edges, uint8_t *bits, int height, int width, int n_frames,
+                                hipStream_t stream)
+{
+    const int row_bytes = (width + 7) / 8;
+    const size_t n_bytes = (size_t)n_frames * (size_t)height * (size_t)row_bytes;
+    if (n_bytes == 0) return hipSuccess;
+    const int vec_ok = (width % 8 == 0) && (((uintptr_t)edges & 15u) == 0);
+    hipLaunchKernelGGL(edges_to_bits_kernel, dim3(grid_for(n_bytes, 256)), dim3(256), 0, stream, edges, bits, width,
+                       row_bytes, n_bytes, vec_ok);
+    return hipGetLastError();
+}
+
 // Publishes flags[0..1] and a sequence number in host-visible (pinned, mapped) memory: the host polls host[2].
 __global__ void hyst_publish_kernel(const unsigned *__restrict__ flags, unsigned *host, unsigned seq)
 {

@@ -189,6 +189,13 @@ int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_f
  * this one. */
 int canny_hip_canny_batch_u8(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
                              int max_val, int height, int width, unsigned char *edges);
+/* Same, with the edge maps as BIT maps: 1 = EDGE, 0 = NOEDGE, rows packed MSB-first (pixel 0 of a row is bit 7 of the
+ * row's first byte, as in PBM "P4" files and numpy.packbits) and padded to whole bytes, so frame i occupies
+ * height * ((width + 7) / 8) bytes at bits + i * that.  The map only ever holds two values (src/utils.h:5-6), so
+ * nothing is lost, and the download shrinks from 2 bytes per pixel to 1/8: the batch then runs at the rate frames can be
+ * UPLOADED (one byte per pixel).  Not in the reference; the next step after SURVEY.md 8(f) item 2. */
+int canny_hip_canny_batch_bits(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                               int max_val, int height, int width, unsigned char *bits);
 /* Shards n_frames by contiguous ranges over n_devices GPUs (devices 0..n_devices-1), one host thread and one
  * context per GPU, each running the batch pipeline above on its shard; no collective (BASELINE config 5: the
  * reference has no multi-GPU path, frames are independent).  n_devices <= 0 = all.  The per-device contexts
@@ -200,6 +207,8 @@ int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sig
                               int height, int width, short *edges, int n_devices);
 int canny_hip_canny_multi_gpu_u8(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
                                  int height, int width, unsigned char *edges, int n_devices);
+int canny_hip_canny_multi_gpu_bits(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
+                                   int height, int width, unsigned char *bits, int n_devices);
 /* Process-wide options of the sharder: "tune_batch_workers" / "tune_batch_chunk_mb" / "tune_batch_chunk_frames" /
  * "tune_batch_pipe_mode"
  * (applied to every shard's pipeline), "numa_affinity" 1 (default) / 0, "allow_device_reuse" 0 (default) / 1:
@@ -258,6 +267,9 @@ int canny_hip_dev_canny_stream_flush(canny_hip_ctx *ctx);
  * by one more elementwise kernel (this entry point exists for transfers, not for speed on the device). */
 int canny_hip_dev_canny_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
                            int height, int width, int n_frames, unsigned char *d_edges);
+/* ... and with a bit map as output (layout as canny_hip_canny_batch_bits: n_frames * height * ((width + 7) / 8) bytes). */
+int canny_hip_dev_canny_bits(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
+                             int height, int width, int n_frames, unsigned char *d_bits);
 
 /* ---- per-stage HIP-event timing (events are recorded on the launch stream) ----------------- */
 int canny_hip_profile_enable(canny_hip_ctx *ctx, int on);

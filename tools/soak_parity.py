@@ -91,8 +91,8 @@ def main():
                 "tune_batch_workers": int(rng.integers(0, 4))}
         for k, v in opts.items():
             ctx.set_option(k, v)
-        path = int(rng.integers(0, 4))
-        name = ("canny per frame", "canny_batch s16", "canny_batch u8", "stage calls")[path]
+        path = int(rng.integers(0, 5))
+        name = ("canny per frame", "canny_batch s16", "canny_batch u8", "stage calls", "canny_batch bits")[path]
         what = dict(seed=args.seed, case=cases, h=h, w=w, n=n, kind=kind, sigma=sigma, lo=lo, hi=hi, path=name, **opts)
         try:
             if path == 0:
@@ -101,6 +101,8 @@ def main():
                 got = list(ctx.canny_batch(frames, sigma, lo, hi))
             elif path == 2:
                 got = [g.astype(np.int16) for g in ctx.canny_batch(frames, sigma, lo, hi, u8=True)]
+            elif path == 4:
+                got = list(capi.unpack_bits(ctx.canny_batch(frames, sigma, lo, hi, bits=True), w))
             else:
                 got = []
                 for f in frames:

@@ -2,9 +2,9 @@
 """Randomised parity soak: the HIP path against the oracle on random shapes, pictures, sigmas, thresholds, batch sizes
 and tuning options, for a bounded time (default 300 s).  The -m gpu tests fix their cases; this draws new ones -- the
 point is the rare interleaving (the per-frame tail kernel, the three-slot batch pipeline, context reuse across
-shapes), not coverage of a feature.  tools/ may use oracle/ like the tests do: this is a checker, not product code.
+shapes), not coverage of a feature.  Not collected by pytest (no test_ prefix): run it by hand on a GPU box.
 
-    python tools/soak_parity.py [--seconds 300] [--seed N] [--max-pixels 1500000]
+    python tests/soak_parity.py [--seconds 300] [--seed N] [--max-pixels 1500000]
 
 Prints one line per 50 cases and a JSON summary; exits 1 on the first mismatch, with the case's parameters and seed.
 """

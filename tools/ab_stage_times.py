@@ -65,8 +65,8 @@ def main():
         if all("sobel_nms_u8in_ms" in x for x in runs):
             extra = f"  sobel_nms(u8 in) {med(lambda x: x['sobel_nms_u8in_ms'])}  gaussian(u8 out) {med(lambda x: x['gaussian_u8_ms'])}"
         extra += f"  1 frame: latency {med(lambda x: x.get('single_frame_latency_ms'))} stream {med(lambda x: x.get('single_frame_stream_ms'))}"
-        par = [x.get("parity") for x in runs if "parity" in x]
-        print(f"{name:28s} canny wall {wall}  gaussian {g}  sobel+nms+classify {s}  propagate {pr}  sobel_nms(s16) {s16}{extra}  parity={par}")
+        par = sorted({x["edges_sha256"] for x in runs if "edges_sha256" in x})  # equal across variants = same edge map
+        print(f"{name:28s} canny wall {wall}  gaussian {g}  sobel+nms+classify {s}  propagate {pr}  sobel_nms(s16) {s16}{extra}  edges_sha256={par}")
 
 
 if __name__ == "__main__":

@@ -23,7 +23,9 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--sigma", type=float, default=1.4)
     ap.add_argument("--opt", action="append", default=[])
-    ap.add_argument("--check", action="store_true", help="compare frame 0 with the oracle")
+    ap.add_argument("--check", action="store_true",
+                    help="print the SHA-256 of frame 0's edge map (an A/B of library builds compares them; parity with "
+                         "the oracle is the test-suite's job, tests/)")
     a = ap.parse_args()
     H, W, F = a.height, a.width, a.frames
     ctx = capi.Context(0)
@@ -64,10 +66,10 @@ def main():
     _, st = run(lambda: ctx.dev_canny(d_img, a.sigma, 50, 150, H, W, F, d_out), a.steps)
     out["canny_stages_ms"] = st
     if a.check:
-        import oracle
+        import hashlib
         got = np.empty((H, W), np.int16)
         ctx.d2h(got, d_out)
-        out["parity"] = bool(np.array_equal(got, oracle.canny(base[0], a.sigma, 50, 150)))
+        out["edges_sha256"] = hashlib.sha256(got.tobytes()).hexdigest()[:16]
     ctx.dev_gaussian(d_img, a.sigma, H, W, F, d_sm)
     _, st = run(lambda: ctx.dev_sobel_nms(d_sm, H, W, F, d_out), a.steps)
     out["sobel_nms_s16_ms"] = st.get("sobel_nms")

@@ -117,6 +117,15 @@ def main():
         "frames": N, "pinned_seconds": round(tp8, 4), "pinned_Mpix_s": round(N * H * W / tp8 / 1e6, 1),
         "pinned_GB_s_both_directions": round((frames.nbytes + pin_out8.nbytes) / tp8 / 1e9, 2),
         "equals_s16_maps": same8}
+    # ... and as bit maps (canny_hip_canny_batch_bits): 1.125 bytes per pixel over PCIe, upload-bound
+    pin_bits = ctx.pinned_array((N, H, (W + 7) // 8), np.uint8)
+    ctx.canny_batch(pin_in[:32], 1.0, 50, 150, out=pin_bits[:32], bits=True)
+    tpb, _ = best_of(lambda: ctx.canny_batch(pin_in, 1.0, 50, 150, out=pin_bits, bits=True))
+    out["C3_batch_1080p_sigma1.0_bit_maps"] = {
+        "frames": N, "pinned_seconds": round(tpb, 4), "pinned_Mpix_s": round(N * H * W / tpb / 1e6, 1),
+        "h2d_GB_s": round(frames.nbytes / tpb / 1e9, 2),
+        "equals_s16_maps": bool(np.array_equal(np.unpackbits(pin_bits[:64], axis=-1)[..., :W].astype(np.int16) * 255,
+                                               edges[:64]))}
     out["C3_batch_1080p_sigma1.0"] = {
         "frames": N, "pageable_seconds": round(t, 4), "pageable_Mpix_s": round(N * H * W / t / 1e6, 1),
         "pinned_seconds": round(tp, 4), "pinned_Mpix_s": round(N * H * W / tp / 1e6, 1),

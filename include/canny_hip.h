@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define CANNY_HIP_VERSION 100        /* 0.1.0 */
+#define CANNY_HIP_VERSION 200        /* 0.2.0: + batch u8 / bit maps, multi-GPU options, host_register, async dev_canny */
 #define CANNY_HIP_MAX_WINDOW 129     /* largest Gaussian window (sigma <= 21.33) */
 
 typedef struct canny_hip_ctx canny_hip_ctx;

@@ -126,3 +126,25 @@ def test_multi_gpu_options_are_validated_without_a_gpu():
     with pytest.raises(capi.CannyHipError):
         capi.multi_gpu_set_option("allow_device_reuse", 2)
     capi.multi_gpu_release()  # nothing cached: a no-op
+
+
+def test_public_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: canny_hip.h and canny_frames.h must compile as strict C99 (no C++ in the signatures),
+    and a C program must link against the libraries with nothing but those headers."""
+    src = tmp_path / "user.c"
+    src.write_text('#include "canny_hip.h"\n#include "canny_frames.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    int n = -1;\n'
+                   '    int st = canny_hip_device_count(&n);\n'
+                   '    int h = 0, w = 0;\n'
+                   '    int fr = canny_frames_jpeg_info("xx", 2, &h, &w);\n'
+                   '    printf("%d %d %d %d\\n", canny_hip_version(), st, n >= 0, fr);\n'
+                   '    return 0;\n}\n')
+    exe = tmp_path / "user"
+    pkg = os.path.join(ROOT, "canny_edge_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           str(src), "-L" + pkg, "-lcanny_utils", "-lcanny_hip", "-Wl,-rpath," + pkg, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    version, _status, counted, frames_status = out.stdout.split()
+    assert int(version) >= 200 and counted == "1" and frames_status == "2"   # "xx" is not a JPEG: CANNY_FRAMES_ERR_FORMAT

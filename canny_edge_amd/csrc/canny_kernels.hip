@@ -488,10 +488,12 @@ __device__ __forceinline__ TileIn load_tile(int t, int lane, const uint64_t *__r
 // c = this lane's word of the tile's connectable plane (the caller has checked that the tile has any), in = the
 // tile as load_tile() returned it.
 // to_frame: neighbours are queued in their FRAME's queue (for hyst_tail_kernel) instead of the batch-wide one.
-__device__ __forceinline__ void process_tile(int t, int lane, uint64_t *__restrict__ strong, const HystSched &sch,
-                                             unsigned *__restrict__ last_change, int iter, const HystGeom &g,
-                                             int16_t *__restrict__ edges, int edge_value, uint64_t c,
-                                             const TileIn &in, bool to_frame = false)
+// push(nb): schedules tile nb for sweep iter + 1 (once per sweep); called by lane 0 only.
+template <class Push>
+__device__ __forceinline__ void process_tile_with(int t, int lane, uint64_t *__restrict__ strong,
+                                                  unsigned *__restrict__ last_change, int iter, const HystGeom &g,
+                                                  int16_t *__restrict__ edges, int edge_value, uint64_t c,
+                                                  const TileIn &in, Push push_tile)
 {
     const int tpf = g.tiles_x * g.tiles_y;
     const int tt = t % tpf;
@@ -547,16 +549,9 @@ __device__ __forceinline__ void process_tile(int t, int lane, uint64_t *__restri
         if (lane == 0) {
             // queue every neighbour whose facing border changed for the next sweep (once per sweep)
             const unsigned nxt = (unsigned)iter + 1u;
-            unsigned *q = (nxt & 1u) ? sch.queue1 : sch.queue0;
-            unsigned *cnt = sch.count + nxt % 3u;
-            if (to_frame) {
-                const int f = t / tpf;
-                q = ((nxt & 1u) ? sch.fq1 : sch.fq0) + (size_t)f * tpf;
-                cnt = sch.fcount + 4 * (size_t)f + nxt % 3u;
-            }
             bool marked = false;
             auto push = [&](int nb) {
-                if (atomicExch(&sch.stamp[nb], nxt) != nxt) q[atomicAdd(cnt, 1u)] = (unsigned)nb;
+                push_tile(nb);
                 marked = true;
             };
             if (hasU && top64) push(t - g.tiles_x);
@@ -570,6 +565,26 @@ __device__ __forceinline__ void process_tile(int t, int lane, uint64_t *__restri
             if (marked) atomicMax(last_change, nxt);
         }
     }
+}
+
+// ... with the queues in global memory (batch-wide, or per frame for the sweep that hands over to hyst_tail_kernel)
+__device__ __forceinline__ void process_tile(int t, int lane, uint64_t *__restrict__ strong, const HystSched &sch,
+                                             unsigned *__restrict__ last_change, int iter, const HystGeom &g,
+                                             int16_t *__restrict__ edges, int edge_value, uint64_t c,
+                                             const TileIn &in, bool to_frame = false)
+{
+    const unsigned nxt = (unsigned)iter + 1u;
+    unsigned *q = (nxt & 1u) ? sch.queue1 : sch.queue0;
+    unsigned *cnt = sch.count + nxt % 3u;
+    if (to_frame) {
+        const int tpf = g.tiles_x * g.tiles_y;
+        const int f = t / tpf;
+        q = ((nxt & 1u) ? sch.fq1 : sch.fq0) + (size_t)f * tpf;
+        cnt = sch.fcount + 4 * (size_t)f + nxt % 3u;
+    }
+    process_tile_with(t, lane, strong, last_change, iter, g, edges, edge_value, c, in, [&](int nb) {
+        if (atomicExch(&sch.stamp[nb], nxt) != nxt) q[atomicAdd(cnt, 1u)] = (unsigned)nb;
+    });
 }
 
 __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__restrict__ strong,
@@ -633,37 +648,64 @@ __global__ __launch_bounds__(256) void hyst_propagate_kernel(uint64_t *__restric
 // grid-wide barrier, no cross-workgroup visibility protocol and no host round trip is needed: after the two
 // batch-wide sweeps that do the bulk of the work (sweep 1 queues into the per-frame queues), this kernel replaces
 // the 6+ nearly empty launches and the host's convergence poll of the multi-launch scheme.
+// The frame's two queues, their counters and the tile stamps live in LDS (48 KB: a frame has at most kTailTiles
+// tiles): a sweep of this kernel is a chain of dependent steps -- how many tiles, which tile, its words, the flood,
+// the pushes -- and with the scheduling words in global memory five of them were L2 round trips or returning atomics
+// (~8 us per sweep, 59 us for the seven tail sweeps of a 4K frame); now the tile's own words are the only ones.
 // Termination: strong bits only ever get set, a tile is queued only when a neighbour's facing border changed, so
 // every frame's queue runs dry after finitely many sweeps; the loop has no other exit and needs none.
-// Visibility: all waves of a workgroup run on one CU and share its L1; __syncthreads() orders their stores and
-// atomics (workgroup scope) before the next sweep's loads.
+// Visibility: all waves of a workgroup run on one CU and share its L1; __syncthreads() orders their stores
+// before the next sweep's loads.
+constexpr int kTailTiles = 4096; // = kTailMaxTiles of canny_capi.hip (checked by launch_hyst_tail)
 __global__ __launch_bounds__(1024) void hyst_tail_kernel(uint64_t *__restrict__ strong, const uint64_t *__restrict__ conn,
                                                          unsigned *__restrict__ sched_words,
                                                          unsigned *__restrict__ last_change, int first_iter, HystGeom g,
                                                          int16_t *__restrict__ edges, int edge_value)
 {
-    __shared__ unsigned s_n;
+    __shared__ unsigned s_queue[2][kTailTiles]; // tile numbers within the frame
+    __shared__ unsigned s_stamp[kTailTiles];    // sweep for which a tile was last queued (dedupes pushes)
+    __shared__ unsigned s_count[2];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
     const int f = blockIdx.x;
     const int tpf = g.tiles_x * g.tiles_y;
+    const int t_base = f * tpf;
     const HystSched sch = make_sched(sched_words, g.tiles());
-    unsigned *const fcount = sch.fcount + 4 * (size_t)f;
-    for (int iter = first_iter;; iter++) {
+    // what sweep first_iter - 1 (batch-wide, to_frame_queues) left for this frame
+    int cur = first_iter & 1;
+    {
+        const unsigned n0 = __hip_atomic_load(sch.fcount + 4 * (size_t)f + first_iter % 3, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned *q0 = (cur ? sch.fq1 : sch.fq0) + (size_t)t_base;
+        for (unsigned i = threadIdx.x; i < n0; i += blockDim.x)
+            s_queue[cur][i] = __hip_atomic_load(q0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)t_base;
+        for (int i = threadIdx.x; i < tpf; i += blockDim.x) s_stamp[i] = 0; // sweeps here are numbered >= 2
         if (threadIdx.x == 0) {
-            s_n = __hip_atomic_load(fcount + iter % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fcount[(iter + 2) % 3] = 0; // the slot sweep iter+1 will append to
+            s_count[cur] = n0;
+            s_count[cur ^ 1] = 0;
         }
-        __syncthreads();
-        const unsigned n = s_n;
-        if (n == 0) break; // uniform: every thread of the workgroup read the same s_n
-        const unsigned *q = ((iter & 1) ? sch.fq1 : sch.fq0) + (size_t)f * tpf;
+    }
+    for (int iter = first_iter;; iter++, cur ^= 1) {
+        __syncthreads(); // the previous sweep's stores and pushes (or the set-up above) are complete
+        const unsigned n = s_count[cur];
+        __syncthreads(); // everybody has read n
+        if (n == 0) break; // uniform
+        if (threadIdx.x == 0) s_count[cur] = 0; // this sweep appends to the other queue, sweep iter + 1 to this one
+        unsigned *const q_next = s_queue[cur ^ 1];
+        unsigned *const n_next = &s_count[cur ^ 1];
+        const unsigned nxt = (unsigned)iter + 1u;
         for (unsigned i = (unsigned)wave; i < n; i += (unsigned)n_waves) {
-            const int t = (int)__hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            propagate_tile(t, lane, strong, conn, sch, last_change, iter, g, edges, edge_value,
-                           conn[(size_t)t * kTile + lane], /*to_frame=*/true);
+            const int t = t_base + (int)s_queue[cur][i];
+            // the tile's connectable word and its strong words + halo are requested together (a queued tile nearly
+            // always has connectable pixels: it was queued because a neighbour's border towards it changed)
+            const uint64_t c = conn[(size_t)t * kTile + lane];
+            const TileIn in = load_tile(t, lane, strong, g);
+            if (!__any(c != 0)) continue;
+            process_tile_with(t, lane, strong, last_change, iter, g, edges, edge_value, c, in, [&](int nb) {
+                const unsigned loc = (unsigned)(nb - t_base);
+                if (atomicExch(&s_stamp[loc], nxt) != nxt) q_next[atomicAdd(n_next, 1u)] = loc;
+            });
         }
-        __syncthreads(); // this sweep's stores and queue pushes are complete (and s_n may be rewritten)
     }
 }
 
@@ -1023,7 +1065,7 @@ hipError_t launch_hyst_publish(const unsigned *flags, unsigned *host_flags_dev, 
 hipError_t launch_hyst_tail(uint64_t *strong, const uint64_t *conn, unsigned *sched, unsigned *last_change,
                             int first_iter, const HystGeom &g, hipStream_t stream, int16_t *edges, int edge_value)
 {
-    if (g.n_frames < 1 || first_iter < 1) return hipErrorInvalidValue;
+    if (g.n_frames < 1 || first_iter < 1 || g.tiles_x * g.tiles_y > kTailTiles) return hipErrorInvalidValue;
     // one workgroup per frame; 16 waves while a frame has enough tiles to keep them busy
     const int tpf = g.tiles_x * g.tiles_y;
     const unsigned threads = tpf >= 256 ? 1024u : (tpf >= 64 ? 512u : 256u);

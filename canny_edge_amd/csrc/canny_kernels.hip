@@ -31,6 +31,14 @@ __device__ __forceinline__ uint64_t shfl_down_u64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// the same for a wave-uniform lane number: two v_readlane_b32, no LDS crossbar
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int uniform_lane)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, uniform_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), uniform_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint64_t lane_u64(uint64_t v, int src_lane)
 {
     unsigned lo = __shfl((unsigned)v, src_lane), hi = __shfl((unsigned)(v >> 32), src_lane);
@@ -488,7 +496,8 @@ __device__ __forceinline__ TileIn load_tile(int t, int lane, const uint64_t *__r
 // c = this lane's word of the tile's connectable plane (the caller has checked that the tile has any), in = the
 // tile as load_tile() returned it.
 // to_frame: neighbours are queued in their FRAME's queue (for hyst_tail_kernel) instead of the batch-wide one.
-// push(nb): schedules tile nb for sweep iter + 1 (once per sweep); called by lane 0 only.
+// push(nb): schedules tile nb for sweep iter + 1 (once per sweep); called by up to eight lanes at once, each with a
+// different neighbour tile.
 template <class Push>
 __device__ __forceinline__ void process_tile_with(int t, int lane, uint64_t *__restrict__ strong,
                                                   unsigned *__restrict__ last_change, int iter, const HystGeom &g,
@@ -530,40 +539,48 @@ __device__ __forceinline__ void process_tile_with(int t, int lane, uint64_t *__r
     }
 
     const uint64_t chg = s ^ s0;
-    if (__any(chg != 0)) {
+    const uint64_t rows_changed = __ballot(chg != 0); // bit r: row r of the tile gained pixels
+    if (rows_changed != 0) {
         strong[base + lane] = s;
-        if (edges && ty * kTile + lane < g.height) { // a handful of pixels per row at most: plain 2-byte stores
+        if (edges) {
+            // (padding bits are never connectable, so every set bit lies inside the image; the row and column tests
+            // only keep a corrupted plane from turning into an out-of-bounds store)
             const int f = t / tpf;
-            int16_t *rowp = edges + ((size_t)f * g.height + (size_t)(ty * kTile + lane)) * g.width + tx * kTile;
-            // (padding bits are never connectable, so every set bit lies inside the image; the column test only
-            // keeps a corrupted plane from turning into an out-of-bounds store)
-            const int cols = min(kTile, g.width - tx * kTile);
-            for (uint64_t m = chg; m != 0; m &= m - 1) {
-                const int b = __builtin_ctzll(m);
-                if (b < cols) rowp[b] = (int16_t)edge_value;
+            const int cols = min(kTile, g.width - tx * kTile), rows = min(kTile, g.height - ty * kTile);
+            int16_t *const tile0 = edges + ((size_t)f * g.height + (size_t)ty * kTile) * g.width + tx * kTile;
+            if (__popcll(rows_changed) <= 16) {
+                // few rows, possibly long runs in them (a horizontal edge): one store instruction per changed row,
+                // lane = column.  With lane = row a run of 60 promoted pixels is 60 dependent loop trips of one
+                // lane -- 9 k cycles of the 14 k a sweep of hyst_tail_kernel took.
+                for (uint64_t m = rows_changed; m != 0; m &= m - 1) { // wave-uniform
+                    const int r = __builtin_ctzll(m);
+                    const uint64_t word = readlane_u64(chg, r);
+                    if (((word >> lane) & 1ull) != 0 && lane < cols && r < rows)
+                        tile0[(size_t)r * g.width + lane] = (int16_t)edge_value;
+                }
+            } else if (lane < rows) { // many rows (a vertical or diagonal edge: a pixel or two per row): lane = row
+                int16_t *const rowp = tile0 + (size_t)lane * g.width;
+                for (uint64_t m = chg; m != 0; m &= m - 1) {
+                    const int b = __builtin_ctzll(m);
+                    if (b < cols) rowp[b] = (int16_t)edge_value;
+                }
             }
         }
-        const uint64_t top64 = lane_u64(chg, 0);  // changes in the tile's first row
-        const uint64_t bot = lane_u64(chg, 63);   // ... and in its last row
+        // Queue every neighbour whose facing border changed for the next sweep (once per sweep).  Lanes 0..7 take
+        // one neighbour each -- up, down, left, right, then the four corners -- so that the stamp exchange and the
+        // queue append of all of them are in flight together instead of one returning atomic after the other.
+        const uint64_t top64 = readlane_u64(chg, 0);  // changes in the tile's first row
+        const uint64_t bot = readlane_u64(chg, 63);   // ... and in its last row
         const bool anyL = __any((chg & 1ull) != 0), anyR = __any((chg >> 63) != 0);
-        if (lane == 0) {
-            // queue every neighbour whose facing border changed for the next sweep (once per sweep)
-            const unsigned nxt = (unsigned)iter + 1u;
-            bool marked = false;
-            auto push = [&](int nb) {
-                push_tile(nb);
-                marked = true;
-            };
-            if (hasU && top64) push(t - g.tiles_x);
-            if (hasD && bot) push(t + g.tiles_x);
-            if (hasL && anyL) push(t - 1);
-            if (hasR && anyR) push(t + 1);
-            if (hasU && hasL && (top64 & 1ull)) push(t - g.tiles_x - 1);
-            if (hasU && hasR && (top64 >> 63)) push(t - g.tiles_x + 1);
-            if (hasD && hasL && (bot & 1ull)) push(t + g.tiles_x - 1);
-            if (hasD && hasR && (bot >> 63)) push(t + g.tiles_x + 1);
-            if (marked) atomicMax(last_change, nxt);
-        }
+        const int dy = (lane == 0 || lane == 4 || lane == 5) ? -1 : ((lane == 1 || lane == 6 || lane == 7) ? 1 : 0);
+        const int dx = (lane == 2 || lane == 4 || lane == 6) ? -1 : ((lane == 3 || lane == 5 || lane == 7) ? 1 : 0);
+        const uint64_t facing = dy < 0 ? top64 : bot;
+        const bool hit = dy == 0 ? (dx < 0 ? anyL : anyR)
+                                 : (dx == 0 ? facing != 0 : (dx < 0 ? (facing & 1ull) != 0 : (facing >> 63) != 0));
+        const bool there = (dy >= 0 || hasU) && (dy <= 0 || hasD) && (dx >= 0 || hasL) && (dx <= 0 || hasR);
+        const bool want = lane < 8 && hit && there;
+        if (want) push_tile(t + dy * g.tiles_x + dx);
+        if (__any(want) && lane == 0) atomicMax(last_change, (unsigned)iter + 1u);
     }
 }
 

@@ -470,12 +470,23 @@ struct TileIn {
     unsigned ul, ur, dl, dr;      // the four corner pixels
 };
 
-__device__ __forceinline__ TileIn load_tile(int t, int lane, const uint64_t *__restrict__ strong, const HystGeom &g)
+// c: the tile's connectable word of this lane if the caller already has it (kAllHalo otherwise).  A neighbour's pixels
+// can only ever pull pixels of this tile that are connectable AND lie on the border facing that neighbour (gsel =
+// s | (c & nb), and a halo bit enters nb only in the first / last column or row): when the connectable plane has no
+// pixel on a border -- most borders of most tiles: 64 of a tile's 4096 pixels, weak candidates are a few per cent --
+// that neighbour is not read at all.  The left and right neighbours are the expensive ones: a whole tile (512 bytes)
+// each for one bit per row, as much as the tile's own two words.
+constexpr uint64_t kAllHalo = ~0ull;
+__device__ __forceinline__ TileIn load_tile(int t, int lane, const uint64_t *__restrict__ strong, const HystGeom &g,
+                                            uint64_t c = kAllHalo)
 {
     const int tpf = g.tiles_x * g.tiles_y;
     const int tt = t % tpf;
     const int ty = tt / g.tiles_x, tx = tt - ty * g.tiles_x;
-    const bool hasU = ty > 0, hasD = ty < g.tiles_y - 1, hasL = tx > 0, hasR = tx < g.tiles_x - 1;
+    const uint64_t c_top = readlane_u64(c, 0), c_bot = readlane_u64(c, 63); // wave-uniform
+    const bool needL = __any((c & 1ull) != 0), needR = __any((c >> 63) != 0);
+    const bool hasU = ty > 0 && c_top != 0, hasD = ty < g.tiles_y - 1 && c_bot != 0;
+    const bool hasL = tx > 0 && needL, hasR = tx < g.tiles_x - 1 && needR;
     const size_t base = (size_t)t * kTile;
     const size_t rowstep = (size_t)g.tiles_x * kTile; // words between vertically adjacent tiles
     TileIn in;
@@ -486,10 +497,10 @@ __device__ __forceinline__ TileIn load_tile(int t, int lane, const uint64_t *__r
     in.sd = hasD ? strong[base + rowstep] : 0;
     in.lb = hasL ? (unsigned)(strong[base - kTile + lane] >> 63) : 0u;
     in.rb = hasR ? (unsigned)(strong[base + kTile + lane] & 1u) : 0u;
-    in.ul = (hasU && hasL) ? (unsigned)(strong[base - rowstep - kTile + 63] >> 63) : 0u;
-    in.ur = (hasU && hasR) ? (unsigned)(strong[base - rowstep + kTile + 63] & 1u) : 0u;
-    in.dl = (hasD && hasL) ? (unsigned)(strong[base + rowstep - kTile] >> 63) : 0u;
-    in.dr = (hasD && hasR) ? (unsigned)(strong[base + rowstep + kTile] & 1u) : 0u;
+    in.ul = (hasU && hasL && (c_top & 1ull)) ? (unsigned)(strong[base - rowstep - kTile + 63] >> 63) : 0u;
+    in.ur = (hasU && hasR && (c_top >> 63)) ? (unsigned)(strong[base - rowstep + kTile + 63] & 1u) : 0u;
+    in.dl = (hasD && hasL && (c_bot & 1ull)) ? (unsigned)(strong[base + rowstep - kTile] >> 63) : 0u;
+    in.dr = (hasD && hasR && (c_bot >> 63)) ? (unsigned)(strong[base + rowstep + kTile] & 1u) : 0u;
     return in;
 }
 
@@ -614,7 +625,7 @@ __device__ __forceinline__ void propagate_tile(int t, int lane, uint64_t *__rest
     // ever be added, so a tile without a single one (flat regions: most tiles of a natural frame) cannot
     // change: leave before the strong plane and the nine halo loads are touched.
     if (!__any(c != 0)) return;
-    const TileIn in = load_tile(t, lane, strong, g);
+    const TileIn in = load_tile(t, lane, strong, g, c);
     process_tile(t, lane, strong, sch, last_change, iter, g, edges, edge_value, c, in, to_frame);
 }
 

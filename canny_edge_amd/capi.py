@@ -48,6 +48,7 @@ EXPORTS = (
     "canny_hip_multi_gpu_release", "canny_hip_device_local_cpus", "canny_hip_selftest_cpulist_count",
     "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in", "canny_hip_host_register", "canny_hip_host_unregister",
     "canny_hip_canny_batch_bits", "canny_hip_canny_multi_gpu_bits", "canny_hip_dev_canny_bits",
+    "canny_hip_probe_copy",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -70,6 +71,9 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C canny_edge_amd/csrc`); there is no CPU fallback")
+    # The batch pipeline's upload / compute / download streams want hardware queues of their own; HIP reads the variable
+    # when its runtime initialises.  This module is host-application code (the library never touches the environment).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     L = C.CDLL(LIB_PATH)
     i, f, p, sz = C.c_int, C.c_float, C.c_void_p, C.c_size_t
     pp, ip = C.POINTER(C.c_void_p), C.POINTER(C.c_int)
@@ -128,6 +132,7 @@ def load() -> C.CDLL:
         "canny_hip_profile_enable": ([p, i], i),
         "canny_hip_profile_reset": ([p], i),
         "canny_hip_profile_get": ([p, i, C.POINTER(C.c_double), C.POINTER(C.c_long)], i),
+        "canny_hip_probe_copy": ([p, p, p, C.c_size_t, i, C.POINTER(C.c_double)], i),
         "canny_hip_selftest_mag_angle": ([p, i, p, p], i),
         "canny_hip_selftest_div": ([p, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
         "canny_hip_selftest_div_fma": ([p, f, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
@@ -396,6 +401,13 @@ class Context:
     def dev_sobel_nms(self, d_smoothed: int, h: int, w: int, n: int, d_out: int):
         self._check(self._L.canny_hip_dev_sobel_nms(self._h, C.c_void_p(d_smoothed), h, w, n, C.c_void_p(d_out)),
                     "dev_sobel_nms")
+
+    def probe_copy(self, d_src: int, d_dst: int, nbytes: int, launches: int = 10) -> float:
+        """Average device milliseconds of a plain copy of nbytes (measurement aid, see canny_hip_probe_copy)."""
+        ms = C.c_double(0)
+        self._check(self._L.canny_hip_probe_copy(self._h, C.c_void_p(d_src), C.c_void_p(d_dst), nbytes, launches,
+                                                 C.byref(ms)), "probe_copy")
+        return ms.value
 
     def dev_gaussian_u8(self, d_img: int, sigma: float, h: int, w: int, n: int, d_out: int):
         """Gaussian storing the smoothed plane as bytes (the "smoothed_u8" path of canny())."""

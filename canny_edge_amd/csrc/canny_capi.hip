@@ -29,11 +29,10 @@ using namespace canny;
 
 // HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
 // queue serialise.  The batch pipeline needs its upload, compute and download streams on separate queues beside
-// whatever streams the host application has (measured: 25.3 -> 16.7 Gpix/s with six streams on four queues, and a
-// single forgotten helper stream is enough), so the library asks for 8 queues -- when it is loaded before the HIP
-// runtime initialises, and never against a value the user has set.  An application that initialises HIP first sets
-// the variable itself.
-__attribute__((constructor)) static void canny_hip_ask_for_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// whatever streams the host application has (measured: 25.3 -> 16.7 Gpix/s with six streams on four queues).  The
+// variable belongs to the APPLICATION: it has to be in the environment before the HIP runtime initialises
+// (bench.py and Main set it).  The library does not touch the process environment (round 2 did, from
+// a constructor: a process-wide side effect that raced getenv() in other threads of a plugin host).
 
 namespace {
 
@@ -740,6 +739,7 @@ int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma
         ctx->pend.event = ctx->aux_event;
     }
     ctx->last_hyst_iters = 0;
+    ctx->hyst_iters_async = false; // this lane reports through its host flags (finish_pending), not through flags[0]
     if ((rc = lane_launch_chunk(ctx, ctx->pend))) return rc;
     ctx->has_pend = true;
     return CANNY_HIP_OK;
@@ -944,6 +944,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
         for (auto &n : ctx->prof_seen) n = 0;
     } else if (!std::strcmp(name, "profile_stage_mask")) ctx->prof_mask = value ? (unsigned)value : ~0u;
     else if (!std::strcmp(name, "tune_sobel_px") && value <= 1) sobel_nms_set_px_variant(value); // process-wide
+    else if (!std::strcmp(name, "tune_sobel_variant") && value <= 1) sobel_nms_set_arith_variant(value); // process-wide
     else if (!std::strcmp(name, "tune_plane_stores") && value <= 1) sobel_nms_set_plane_store_variant(value); // process-wide
     else if (!std::strcmp(name, "gaussian_fma_div") && value <= 1) gaussian_set_fma_div(value != 0); // process-wide
     else if (!std::strcmp(name, "tune_finalize_mode") && value <= 1) hyst_set_finalize_mode(value);   // process-wide
@@ -962,9 +963,8 @@ int canny_hip_synchronize(canny_hip_ctx *ctx)
 }
 
 const char *canny_hip_last_error(const canny_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
-int canny_hip_last_hysteresis_iterations(const canny_hip_ctx *cctx)
+int canny_hip_last_hysteresis_iterations(canny_hip_ctx *ctx)
 {
-    canny_hip_ctx *ctx = const_cast<canny_hip_ctx *>(cctx);
     if (!ctx) return 0;
     if (ctx->hyst_iters_async && ctx->flags.p) {
         // the tail path never reports to the host: fetch the last sweep that scheduled work (diagnostic, synchronises)
@@ -1781,6 +1781,41 @@ int canny_hip_profile_get(canny_hip_ctx *ctx, int stage, double *total_ms, long 
     if ((rc = profile_collect(ctx))) return rc;
     *total_ms = ctx->total_ms[stage];
     *launches = ctx->launches[stage];
+    return CANNY_HIP_OK;
+}
+
+// ---- measurement aid ------------------------------------------------------------------------------------
+int canny_hip_probe_copy(canny_hip_ctx *ctx, const void *d_src, void *d_dst, size_t nbytes, int launches,
+                         double *avg_ms)
+{
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!d_src || !d_dst || !avg_ms || launches < 1 || launches > 10000 || nbytes < 16 || (nbytes & 15) ||
+        ((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15))
+        return CANNY_HIP_ERR_INVALID;
+    hipEvent_t a = nullptr, b = nullptr;
+    HIP_TRY(ctx, hipEventCreate(&a));
+    {
+        const hipError_t eb = hipEventCreate(&b);
+        if (eb != hipSuccess) {
+            (void)hipEventDestroy(a);
+            return fail(ctx, eb, "hipEventCreate");
+        }
+    }
+    double total = 0.0;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < launches && e == hipSuccess; k++) {
+        // the event pair is attached to the dispatch: the kernel's own begin / end timestamps
+        e = launch_probe_copy(d_src, d_dst, nbytes, ctx->stream, LaunchEvents{a, b});
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        total += ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIP_TRY(ctx, e);
+    *avg_ms = total / launches;
     return CANNY_HIP_OK;
 }
 

@@ -81,6 +81,7 @@ hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, i
 // Fused Sobel+NMS, wave-marching and LDS-free (canny_sobel_nms_march.hip); smoothed must lie in [0,255].
 bool sobel_nms_march_supported(int height, int width);
 void sobel_nms_set_px_variant(int v); // A/B: 0 = 8 pixels per lane, 1 = 4 pixels per lane (more resident waves)
+void sobel_nms_set_arith_variant(int v); // A/B: 0 = f32 marching arithmetic (default), 1 = round 2's packed-i16 kernel
 // A/B (fused kernel): 0 = plane bytes staged in LDS for 8 rows and written as 8-byte words, 1 = direct byte stores
 void sobel_nms_set_plane_store_variant(int v);
 // An event pair attached to one kernel dispatch (hipExtLaunchKernel): that kernel's begin and end timestamps.
@@ -154,6 +155,10 @@ hipError_t launch_fep_classify(const int16_t *cand, const uint8_t *visited, uint
                                const HystGeom &g, int start, int min_val, hipStream_t stream);
 hipError_t launch_fep_finalize(int16_t *cand, uint8_t *visited, const uint64_t *strong, const HystGeom &g, int start,
                                int min_val, hipStream_t stream);
+
+// ---- measurement aid ------------------------------------------------------------------------
+// Plain device copy of nbytes (multiple of 16; both pointers 16-byte aligned): what a 1:1 read/write stream reaches.
+hipError_t launch_probe_copy(const void *src, void *dst, size_t nbytes, hipStream_t stream, const LaunchEvents &ev = {});
 
 // ---- self-test ------------------------------------------------------------------------------
 hipError_t launch_selftest_mag_angle(int lim, int16_t *mags, uint8_t *bins, hipStream_t stream);

@@ -11,6 +11,8 @@
 //     Sobel = clamp in-axis + drop off-axis, NMS / hysteresis = skip.
 #include "canny_kernels.h"
 
+#include <hip/hip_ext.h>
+
 namespace canny {
 
 // ================================================================================================
@@ -1208,6 +1210,32 @@ hipError_t launch_selftest_mag_angle(int lim, int16_t *mags, uint8_t *bins, hipS
 {
     size_t total = (size_t)(2 * lim + 1) * (2 * lim + 1);
     hipLaunchKernelGGL(selftest_mag_angle_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, lim, mags, bins);
+    return hipGetLastError();
+}
+
+
+// ---- measurement aid: a plain device copy -----------------------------------------------------------------------
+// What does a stream that reads N bytes and writes N bytes reach on THIS device?  The roofline of the Sobel+NMS pass
+// is quoted against the 8 TB/s spec; boxes differ by up to 14 % in what a copy reaches (tools/probe_march_pattern.hip),
+// so bench.py times this kernel beside the pass it grades.  Workgroup b moves the 4 KB chunk b (one 16-byte load and one
+// 16-byte store per thread): the fastest of the copy shapes tried (grid-stride loops, 4-64 KB chunks, non-temporal).
+__global__ __launch_bounds__(256) void probe_copy_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) out[i] = in[i];
+}
+hipError_t launch_probe_copy(const void *src, void *dst, size_t nbytes, hipStream_t stream, const LaunchEvents &ev)
+{
+    const size_t n16 = nbytes / 16;
+    if (n16 == 0) return hipSuccess;
+    const size_t blocks = (n16 + 255) / 256;
+    if (blocks > 0x7fffffffu) return hipErrorInvalidValue;
+    if (ev.start && ev.stop)
+        hipExtLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ev.start, ev.stop, 0,
+                              (const uint4 *)src, (uint4 *)dst, n16);
+    else
+        hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4 *)src,
+                           (uint4 *)dst, n16);
     return hipGetLastError();
 }
 

@@ -109,6 +109,20 @@ constexpr int SNM_WPB = 4;          // waves per workgroup (independent of each 
 
 template <int N>
 using IC = std::integral_constant<int, N>;
+#ifndef FLT_WAVES
+#define FLT_WAVES 4
+#endif
+// The f32 kernel's phases are fenced for the instruction scheduler: left alone it interleaves the eight pixels of a row
+// (and the production of one row with the suppression of the previous one) for instruction-level parallelism that a
+// wave on this hardware cannot use (one VALU instruction per ~6 cycles per wave whatever the dependences),
+// at 150-170 VGPRs; in groups of FLT_GROUP pixels the same code needs under 128.
+#ifndef FLT_GROUP
+#define FLT_GROUP 2
+#endif
+#ifndef FLT_CARRIERS
+#define FLT_CARRIERS 1 // 1: one v_perm_b32-packed bin carrier per pixel; 2: the two floats themselves
+#endif
+#define FLT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 struct StripJob {
     const int16_t *fin;
@@ -482,6 +496,331 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
     if (STAGE) stage_flush_segment();
 }
 
+// ---- f32 marching variant (round 3; the default) ----------------------------------------------------------------
+// Same strip / segment / lane geometry, same loads, stores and plane staging as march_strip above; what differs is the
+// arithmetic between the row load and the row store, rebuilt around what a vector instruction COSTS on gfx950
+// (tools/valu_issue_bench.hip, DESIGN.md "instruction classes"): plain f32 add/mul/fma, 32-bit integer add/sub,
+// and/or/xor, v_ashrrev_i32 and the 16-bit max issue every ~2.3 cycles per SIMD; everything packed (v_pk_*), every
+// SDWA / DPP form, v_cvt_*, v_cmp_*, v_cndmask, v_addc and the VOP3-only integer ops take ~4.2.  The packed-i16 kernel
+// spends ~20 of its 28.7 instructions per pixel in the slow class; this one ~7 of 30:
+//   * one v_cvt_f32_ubyteN per pixel (the smoothed plane lies in [0,255]: byte 0 / byte 2 of an s16 pair, or the four
+//     bytes of a dword in the u8 form), then every Sobel step is an exact f32 add or fma on integers < 2^11:
+//       vertical first (no lane crossing):  a = s[y-1] + 2 s[y] + s[y+1],  b = s[y+1] - s[y-1]
+//       horizontal:                         gx = a[x+1] - a[x-1],          gy = b[x-1] + 2 b[x] + b[x+1]
+//     (the neighbouring lanes' a / b arrive through DPP shifts folded into the four adds that need them);
+//   * magnitude: floor(sqrt(n)) = low 16 bits of (sqrt(n + 1/2) + (2^23 - 1/2)) -- the float add puts the integer part
+//     into the mantissa (the sum lies in [2^23, 2^24), where one ulp is 1, and sqrt(n + 1/2) is never within rounding
+//     of an integer: DESIGN.md 4.3), the 16-bit maximum that raises the magnitude to the threshold floor discards the
+//     exponent bits: no v_cvt_i32_f32;
+//   * bins: the signs of Q - P and Q + P (never zero: Q has a fractional part of 1/4) travel to the NMS step as the two
+//     floats themselves; there v_ashrrev_i32 turns each into a lane mask IN A VGPR and three v_bfi_b32 select
+//     the neighbour maximum -- no v_cmp, no v_cndmask, no SGPR lane masks, no s_nop hazard pads;
+//   * classify: (nsel - mc) and (hi1 - mc) are negative iff the pixel is connectable / strong; v_alignbit_b32 shifts
+//     each sign bit into its plane byte (one instruction per bit instead of v_cmp + v_addc).
+// State per lane: 16 floats of input rows, 30 magnitudes, 16 bin floats, 12 prefetch registers: under 128 VGPRs, so a
+// SIMD holds four waves instead of three.
+__device__ __forceinline__ float f_from_left(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float f_from_right(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+// (m & a) | (~m & b) as ONE v_bfi_b32 (the compiler's pattern match is not guaranteed for constants it can fold)
+__device__ __forceinline__ int bfi(int m, int a, int b)
+{
+    int r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+// acc = 2 * acc + (d < 0): the sign bit of d shifted into acc
+__device__ __forceinline__ unsigned push_sign(unsigned acc, int d)
+{
+    return __builtin_amdgcn_alignbit(acc, (unsigned)d, 31);
+}
+
+template <bool COL_EDGE, bool ROW_EDGE, bool PLANES, bool LDS_PLANES, bool IN_U8>
+__device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_mem, const uint4 *edge_lut = nullptr)
+{
+    constexpr int NP = 4, PX = 8;
+    const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend;
+    const bool full8 = x0 >= 0 && x0 + PX - 1 < W; // all of this lane's pixels are inside the image
+    const bool owner = jb.lane >= 1 && jb.lane <= 62 && x0 < W;
+
+    // lane-varying border constants (COL_EDGE only).  Out-of-image columns load as zero, so a = b = 0 there:
+    // "columns dropped" (gy) needs nothing, "column clamp" (gx) is gx -= a[0] at column 0 and gx += a[e] at column W-1.
+    // Two registers carry all of it: elast = index of column W-1 relative to this lane's pixel 0 (>= 7: every pixel
+    // inside; -1: every pixel outside, also for the halo lane left of column 0), from which "pixel e is inside" is the
+    // sign of e - 1 - elast, and fix_l.
+    const float fix_l = (COL_EDGE && x0 == 0) ? 1.0f : 0.0f; // column 0 is always pixel 0 of a lane (x0 % 8 == 0)
+    int elast = (x0 < 0) ? -1 : W - 1 - x0;
+    if (COL_EDGE) asm volatile("" : "+v"(elast)); // keep the eight masks out of registers: recomputed per row
+    auto inside = [&](int e) { return (e - 1 - elast) >> 31; }; // all ones iff x0 + e lies inside the image
+
+    auto load_row = [&](int r, uint32_t (&p)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) p[i] = 0u;
+        if (ROW_EDGE && (r < 0 || r >= H)) return; // wave-uniform: virtual rows are zero
+        if (IN_U8) {
+            const uint8_t *src8 = jb.fin8 + (size_t)r * W + x0;
+            if (!COL_EDGE || full8) {
+                __builtin_memcpy(p, src8, 8); // one 8-byte load
+            } else if (x0 + PX - 1 >= 0 && x0 < W) {
+#pragma unroll
+                for (int e = 0; e < PX; e++) {
+                    int x = x0 + e;
+                    if (x >= 0 && x < W) p[e >> 2] |= (uint32_t)src8[e] << (8 * (e & 3));
+                }
+            }
+            return;
+        }
+        const int16_t *src = jb.fin + (size_t)r * W + x0;
+        if (!COL_EDGE || full8) {
+            __builtin_memcpy(p, src, 4 * NP); // one 16-byte load
+        } else if (x0 + PX - 1 >= 0 && x0 < W) {
+#pragma unroll
+            for (int e = 0; e < PX; e++) {
+                int x = x0 + e;
+                if (x >= 0 && x < W) p[e >> 1] |= (uint32_t)(uint16_t)src[e] << (16 * (e & 1));
+            }
+        }
+    };
+
+    // floor of every stored magnitude and the value of a pixel NMS must skip: see march_strip
+    int skip = PLANES ? jb.lo1 : 0;
+    int hi1v = PLANES ? jb.hi1 : 0; // VGPR copies: an SGPR operand would make the instruction slow class
+    asm volatile("" : "+v"(skip), "+v"(hi1v));
+
+    float F[3][PX];      // input rows r, r-1, r-2 as floats
+    int M[3][PX + 2];    // magnitudes of rows r-1, r-2, r-3; [0] and [PX+1] are the neighbours' edge pixels
+    int cz[3][PX];       // bin carriers (signs of Q - P and Q + P) of the rows r-1 (being produced) and r-2 (consumed)
+#if FLT_CARRIERS != 1
+    int cy[3][PX];
+#endif
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int e = 0; e < PX; e++) {
+            F[a][e] = 0.0f;
+            cz[a][e] = 0;
+        }
+#pragma unroll
+        for (int e = 0; e < PX + 2; e++) M[a][e] = skip;
+    }
+
+    // ---- plane bytes through LDS: identical to march_strip ---------------------------------------------------------
+    constexpr bool STAGE = LDS_PLANES && PLANES;
+    constexpr unsigned kStagePitch = 72, kStageRows = SNM_STAGE_ROWS, kStagePlane = kStageRows * kStagePitch;
+    uint8_t *const stage = stage_mem;
+    unsigned stage_col = 0;
+    int st_o = 0, st_e = 0, st_w0 = 0;
+    if (STAGE) {
+        const int strip_b0 = (x0 - (jb.lane - 1) * PX) >> 3;
+        const int nb = COL_EDGE ? max(0, min(62, (W >> 3) - strip_b0)) : 62;
+        st_o = strip_b0 & 7;
+        st_w0 = strip_b0 >> 3;
+        st_e = st_o + nb;
+        stage_col = jb.lane == 0 ? 71u : (unsigned)(st_o + jb.lane - 1);
+    }
+    auto stage_flush_segment = [&]() {
+        const int y = ybeg + jb.lane; // lane = row
+        const bool row_ok = y < yend;
+        const unsigned lrow = (unsigned)jb.lane * kStagePitch;
+        const unsigned grow = (unsigned)(y >> 6) * (unsigned)jb.tiles_x * 512u + (unsigned)(y & 63) * 8u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int wf0 = (st_o + 7) >> 3, wf1 = st_e >> 3;
+        for (int k = wf0; k < wf1; k++) {
+            if (row_ok) {
+                const unsigned g = grow + (unsigned)(st_w0 + k) * 512u;
+                *reinterpret_cast<uint64_t *>(jb.pconn + g) = *reinterpret_cast<const uint64_t *>(stage + lrow + 8 * k);
+                *reinterpret_cast<uint64_t *>(jb.pstrong + g) =
+                    *reinterpret_cast<const uint64_t *>(stage + kStagePlane + lrow + 8 * k);
+            }
+        }
+        auto leftover = [&](int i) {
+            if (!row_ok) return;
+            const unsigned g = grow + (unsigned)(st_w0 + (i >> 3)) * 512u + (unsigned)(i & 7);
+            if (!COL_EDGE) {
+                *reinterpret_cast<uint16_t *>(jb.pconn + g) = *reinterpret_cast<const uint16_t *>(stage + lrow + i);
+                *reinterpret_cast<uint16_t *>(jb.pstrong + g) =
+                    *reinterpret_cast<const uint16_t *>(stage + kStagePlane + lrow + i);
+            } else {
+                jb.pconn[g] = stage[lrow + i];
+                jb.pstrong[g] = stage[kStagePlane + lrow + i];
+            }
+        };
+        constexpr int kStep = COL_EDGE ? 1 : 2;
+        const int head_end = min(8 * wf0, st_e), tail_beg = max(8 * wf1, head_end);
+        for (int i = st_o; i < head_end; i += kStep) leftover(i);
+        for (int i = tail_beg; i < st_e; i += kStep) leftover(i);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
+    auto step = [&](auto ph, int r, const uint32_t (&praw)[NP]) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr int k2 = PH % 3, k1 = (PH + 2) % 3, k0 = (PH + 1) % 3; // F of rows r, r-1, r-2
+        constexpr int m2 = PH % 3, m1 = (PH + 2) % 3, m0 = (PH + 1) % 3; // M of rows r-1, r-2, r-3; carriers alike
+
+        // ---- row r as floats (exact: the plane's values are 0..255) ----------------------------------------------
+#pragma unroll
+        for (int e = 0; e < PX; e++) {
+            const uint32_t w = IN_U8 ? praw[e >> 2] >> (8 * (e & 3)) : praw[e >> 1] >> (16 * (e & 1));
+            F[k2][e] = (float)(w & 0xffu); // v_cvt_f32_ubyteN
+        }
+
+        // ---- gradient, magnitude and bin carriers for row y1 = r-1 -----------------------------------------------
+        const int y1 = r - 1;
+        if (!ROW_EDGE || (y1 >= 0 && y1 < H)) {
+            float a[PX], b[PX];
+#pragma unroll
+            for (int e = 0; e < PX; e++) {
+                // gx: rows outside the image are dropped (their floats are zero); gy: the row is clamped
+                a[e] = __fadd_rn(__fmaf_rn(2.0f, F[k1][e], F[k0][e]), F[k2][e]);
+                const float up = (ROW_EDGE && y1 == 0) ? F[k1][e] : F[k0][e];
+                const float dn = (ROW_EDGE && y1 == H - 1) ? F[k1][e] : F[k2][e];
+                b[e] = __fsub_rn(dn, up);
+            }
+            const float a_l = f_from_left(a[PX - 1]), a_r = f_from_right(a[0]);
+            const float b_l = f_from_left(b[PX - 1]), b_r = f_from_right(b[0]);
+            FLT_SCHED_FENCE();
+#pragma unroll
+            for (int e = 0; e < PX; e++) {
+                if (e && e % FLT_GROUP == 0) FLT_SCHED_FENCE();
+                const float al = e ? a[e - 1] : a_l, ar = e < PX - 1 ? a[e + 1] : a_r;
+                const float bl = e ? b[e - 1] : b_l, br = e < PX - 1 ? b[e + 1] : b_r;
+                float gx = __fsub_rn(ar, al);
+                if (COL_EDGE) {
+                    if (e == 0) gx = __fmaf_rn(-fix_l, a[0], gx); // column clamp at 0 ...
+                    // ... and at W-1: pixel e is the last column iff it is inside and pixel e + 1 is not
+                    gx = __fadd_rn(gx, __int_as_float(__float_as_int(a[e]) & (inside(e) ^ inside(e + 1))));
+                }
+                const float gy = __fadd_rn(__fmaf_rn(2.0f, b[e], bl), br);
+                // all exact in f32 (integers and quarters below 2^24):
+                //   Ah = gx^2 + 1/2,  nh = gx^2 + gy^2 + 1/2,  Q = (gx^2 - gy^2)/2 + 1/4,  P = gx gy
+                const float Ah = __fmaf_rn(gx, gx, 0.5f);
+                const float nh = __fmaf_rn(gy, gy, Ah);
+                const float mb = __fadd_rn(__builtin_amdgcn_sqrtf(nh), 8388607.5f); // 2^23 + floor(sqrt(n))
+                int m = __float_as_int(mb);
+                if (COL_EDGE) m &= inside(e); // out-of-image magnitudes become the floor
+                M[m2][e + 1] = PLANES ? max_u16(m, skip) : (m & 0xffff);
+                const float Q = __fmaf_rn(nh, -0.5f, Ah);
+                const float qm = __fmaf_rn(-gx, gy, Q); // Q - P < 0  <=>  not (X - Y >= 0)
+                const float qp = __fmaf_rn(gx, gy, Q);  // Q + P < 0  <=>  not (X + Y >= 0)
+#if FLT_CARRIERS == 1
+                // one carrier per pixel: byte 3 = sign of Q - P, bytes 0-2 = sign of Q + P, eight copies each
+                // (v_perm_b32 selectors 11 / 9 replicate bit 31 of the first / second source)
+                cz[m2][e] = (int)__builtin_amdgcn_perm(__float_as_uint(qm), __float_as_uint(qp), 0x0b090909u);
+                // Materialise the carrier HERE: its only use is in the next row's step, and the optimiser otherwise
+                // sinks its computation behind that row's NMS branch and keeps gx, gy, Ah and nh alive instead.
+                asm volatile("" : "+v"(cz[m2][e]));
+#else
+                cz[m2][e] = __float_as_int(qm);
+                cy[m2][e] = __float_as_int(qp);
+                asm volatile("" : "+v"(cz[m2][e]), "+v"(cy[m2][e]));
+#endif
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < PX; e++) M[m2][e + 1] = skip; // rows outside the image are skipped by NMS
+        }
+        M[m2][0] = (int)from_left((uint32_t)M[m2][PX]);
+        M[m2][PX + 1] = (int)from_right((uint32_t)M[m2][1]);
+        FLT_SCHED_FENCE();
+
+        // ---- NMS for row y2 = r-2 --------------------------------------------------------------------------------
+        const int y2 = r - 2;
+        if (y2 >= ybeg && y2 < yend) {
+            uint32_t outp[NP] = {};
+            unsigned cacc = 0, sacc = 0;
+            int keep[PX];
+#pragma unroll
+            for (int ee = 0; ee < PX; ee++) {
+                if (ee && ee % FLT_GROUP == 0) FLT_SCHED_FENCE();
+                const int e = PX - 1 - ee; // last pixel first: pixel e ends up in bit e
+                const int c = e + 1;
+                const int mc = M[m1][c];
+                const int n0 = max_u16(M[m1][c - 1], M[m1][c + 1]);
+                const int n90 = max_u16(M[m0][c], M[m2][c]);
+                const int n45 = max_u16(M[m0][c + 1], M[m2][c - 1]);  // up-right, down-left
+                const int n135 = max_u16(M[m0][c - 1], M[m2][c + 1]); // up-left, down-right
+                // bins are the quadrants of (X + Y, X - Y), see march_strip: 0: both >= 0, 90: both < 0,
+                // 45: X + Y >= 0 > X - Y, 135: the rest.  mv / mu are all ones where the test FAILS.
+                const int mv = cz[m1][e] >> 31; // all 32 bits
+#if FLT_CARRIERS == 1
+                const int mu = cz[m1][e];       // its low 16 bits are the mask; the selected values are 16 bits wide
+#else
+                const int mu = cy[m1][e] >> 31;
+#endif
+                const int na = bfi(mv, n45, n0);   // X - Y >= 0 ? n0 : n45
+                const int nb = bfi(mv, n90, n135); // X - Y >= 0 ? n135 : n90
+                const int nsel = bfi(mu, nb, na);  // X + Y >= 0 ? na : nb
+                const int dc = nsel - mc;          // < 0  <=>  mc > nsel
+                if (PLANES) {
+                    cacc = push_sign(cacc, dc);
+                    sacc = push_sign(sacc, hi1v - mc); // < 0  <=>  mc > hi1; ANDed with cacc below
+                } else {
+                    keep[e] = mc & (dc >> 31);
+                }
+            }
+            if (PLANES) {
+                const unsigned cbits = cacc & 0xffu, sb = sacc & cbits;
+                if (STAGE) {
+                    const uint4 v = edge_lut[sb];
+                    outp[0] = v.x;
+                    outp[1] = v.y;
+                    outp[2] = v.z;
+                    outp[3] = v.w;
+                    const unsigned rowoff = (unsigned)(y2 - ybeg) * kStagePitch;
+                    stage[rowoff + stage_col] = (uint8_t)cbits; // halo lanes write pad columns nobody reads
+                    stage[kStagePlane + rowoff + stage_col] = (uint8_t)sb;
+                    if (owner) store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
+                } else {
+                    const uint32_t tb = sb | (sb << 15);
+#pragma unroll
+                    for (int i = 0; i < NP; i++)
+                        outp[i] = __umul24((tb >> (2 * i)) & 0x00010001u, (uint32_t)jb.edge_value);
+                    if (owner) { // W % 8 == 0: an owner lane's pixels are all inside the image
+                        const unsigned bx = (unsigned)x0 >> 3;
+                        const unsigned off = ((unsigned)(y2 >> 6) * (unsigned)jb.tiles_x + (bx >> 3)) * 512u +
+                                             (unsigned)(y2 & 63) * 8u + (bx & 7u);
+                        jb.pconn[off] = (uint8_t)cbits;
+                        jb.pstrong[off] = (uint8_t)sb;
+                        store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
+                    }
+                }
+            } else if (owner) {
+#pragma unroll
+                for (int i = 0; i < NP; i++) outp[i] = (uint32_t)keep[2 * i] | ((uint32_t)keep[2 * i + 1] << 16);
+                int16_t *dst = jb.fout + (size_t)y2 * W + x0;
+                if (!COL_EDGE || full8) {
+                    store_row<NP>(dst, outp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < PX; e++)
+                        if (x0 + e < W) dst[e] = (int16_t)keep[e];
+                }
+            }
+        }
+    };
+
+    const int rfirst = ybeg - 2;
+    const int rlast = rfirst + 3 * ((yend + 1 - rfirst + 3) / 3) - 1;
+    uint32_t pa[NP], pb[NP], pc[NP];
+    load_row(rfirst, pa);
+    load_row(rfirst + 1, pb);
+    for (int r = rfirst; r <= rlast; r += 3) {
+        load_row(r + 2, pc);
+        step(IC<0>{}, r, pa);
+        load_row(r + 3, pa);
+        step(IC<1>{}, r + 1, pb);
+        load_row(r + 4, pb);
+        step(IC<2>{}, r + 2, pc);
+    }
+    if (STAGE) stage_flush_segment();
+}
+
 } // namespace
 
 struct PlaneArgs { // PLANES instantiation only
@@ -489,8 +828,10 @@ struct PlaneArgs { // PLANES instantiation only
     int tiles_x, tiles_y, lo1, hi1, edge_value;
 };
 
-template <bool PLANES, int NP, bool LDS_PLANES, bool IN_U8 = false>
-__global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const void *__restrict__ in,
+// FLT: the f32 marching arithmetic (fmarch_strip, 8 pixels per lane only) instead of the packed-i16 one.
+template <bool PLANES, int NP, bool LDS_PLANES, bool IN_U8 = false, bool FLT = false>
+__global__ __launch_bounds__(SNM_WPB * 64) __attribute__((amdgpu_waves_per_eu(FLT ? FLT_WAVES : 1)))
+void sobel_nms_march_kernel(const void *__restrict__ in,
                                                                        int16_t *__restrict__ out, int H, int W,
                                                                        int n_strips, int n_segs, int seg_rows,
                                                                        int total_waves, PlaneArgs pl)
@@ -549,7 +890,24 @@ __global__ __launch_bounds__(SNM_WPB * 64) void sobel_nms_march_kernel(const voi
     const bool col_edge = (s == 0) || ((s + 1) * SnmCfg<NP>::SW + SnmCfg<NP>::PX >= W);
     // rows touched: ybeg-2 .. (rounded-up last row) + 2 prefetched  <=  yend + 5
     const bool row_edge = (jb.ybeg < 2) || (jb.yend + 5 >= H);
-    if (col_edge) {
+    if constexpr (FLT) {
+        static_assert(NP == 4, "the f32 variant processes 8 pixels per lane");
+#ifdef PROBE_VARIANT
+        fmarch_strip<(PROBE_VARIANT & 1) != 0, (PROBE_VARIANT & 2) != 0, PLANES, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
+        return;
+#endif
+        if (col_edge) {
+            if (row_edge)
+                fmarch_strip<true, true, PLANES, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
+            else
+                fmarch_strip<true, false, PLANES, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
+        } else {
+            if (row_edge)
+                fmarch_strip<false, true, PLANES, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
+            else
+                fmarch_strip<false, false, PLANES, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
+        }
+    } else if (col_edge) {
         if (row_edge)
             march_strip<true, true, PLANES, NP, LDS_PLANES, IN_U8>(jb, stage_mem, edge_lut);
         else
@@ -566,6 +924,9 @@ bool sobel_nms_march_supported(int height, int width) { return height >= 2 && wi
 
 static int px_variant = 0; // A/B switch "tune_sobel_px": 0 = 8 pixels per lane, 1 = 4 pixels per lane
 void sobel_nms_set_px_variant(int v) { px_variant = v; }
+// A/B switch "tune_sobel_variant": 0 = f32 marching arithmetic (default), 1 = round 2's packed-i16 arithmetic
+static int arith_variant = 0;
+void sobel_nms_set_arith_variant(int v) { arith_variant = v; }
 // A/B switch "tune_plane_stores": 0 = plane bytes staged in LDS and written as words, 1 = direct byte stores
 static int plane_store_variant = 0;
 void sobel_nms_set_plane_store_variant(int v) { plane_store_variant = v; }
@@ -604,6 +965,19 @@ static hipError_t launch_march(const void *smoothed, int16_t *out, const PlaneAr
     unsigned blocks = (unsigned)((waves + SNM_WPB - 1) / SNM_WPB);
     const PlaneArgs pl = planes ? *planes : PlaneArgs{};
     const dim3 grid(blocks), block(SNM_WPB * 64);
+    if (arith_variant == 0 && np == 4) { // the f32 arithmetic: every 8-pixel form
+        const bool lds = planes && plane_store_variant == 0;
+#define CANNY_FLT_LAUNCH(P, L, U)                                                                                      \
+    launch_timed(sobel_nms_march_kernel<P, 4, L, U, true>, grid, block, stream, ev, smoothed, out, height, width,      \
+                 n_strips, n_segs, seg, (int)waves, pl)
+        if (planes && lds && in_u8) CANNY_FLT_LAUNCH(true, true, true);
+        else if (planes && lds) CANNY_FLT_LAUNCH(true, true, false);
+        else if (planes) CANNY_FLT_LAUNCH(true, false, false);
+        else if (in_u8) CANNY_FLT_LAUNCH(false, false, true);
+        else CANNY_FLT_LAUNCH(false, false, false);
+#undef CANNY_FLT_LAUNCH
+        return hipGetLastError();
+    }
     if (in_u8 && planes)
         launch_timed(sobel_nms_march_kernel<true, 4, true, true>, grid, block, stream, ev, smoothed, out, height, width,
                      n_strips, n_segs, seg, (int)waves, pl);

@@ -424,6 +424,11 @@ struct Decoder {
                 st = check_colour_space();
                 if (st) return st;
                 stride = comps[0].blocks_w * 8;
+                // Untrusted header: every 8x8 block costs at least one bit of entropy-coded data per component, so a
+                // file cannot describe more than 8 * size luminance blocks -- refuse before allocating gigabytes for
+                // a 65535 x 65535 header on a tiny file (and before decoding its phantom blocks).
+                if ((unsigned long long)comps[0].blocks_w * comps[0].blocks_h > 8ull * size)
+                    return fail(CANNY_FRAMES_ERR_FORMAT, "frame size implausible for the file size (damaged header)");
                 plane.assign((size_t)stride * comps[0].blocks_h * 8, 0);
             }
             // scan header: which components, which tables
@@ -471,7 +476,9 @@ struct Decoder {
                 const bool luma = &c == &comps[0];
                 const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;
                 const int bw = (cw + 7) / 8, bh = (ch + 7) / 8;
-                for (int by = 0; by < bh; by++)
+                for (int by = 0; by < bh; by++) {
+                    if (br.overrun())
+                        return fail(CANNY_FRAMES_ERR_FORMAT, "entropy-coded data ends early (truncated or damaged file)");
                     for (int bx = 0; bx < bw; bx++) {
                         if (!maybe_restart()) return fail(CANNY_FRAMES_ERR_FORMAT, "missing restart marker (truncated or damaged file)");
                         if (luma) std::memset(coef, 0, sizeof(coef));
@@ -479,12 +486,15 @@ struct Decoder {
                         if (st) return st;
                         if (luma) inverse_dct(coef, plane.data() + (size_t)by * 8 * stride + bx * 8, stride);
                     }
+                }
                 luma_done = luma_done || luma;
             } else {
                 const int mcux = comps[0].blocks_w / comps[0].h, mcuy = comps[0].blocks_h / comps[0].v;
                 bool has_luma = false;
                 for (Component *c : in_scan) has_luma = has_luma || c == &comps[0];
-                for (int my = 0; my < mcuy; my++)
+                for (int my = 0; my < mcuy; my++) {
+                    if (br.overrun()) // once per MCU row: a cut file stops here, not after a scan of zero-bit blocks
+                        return fail(CANNY_FRAMES_ERR_FORMAT, "entropy-coded data ends early (truncated or damaged file)");
                     for (int mx = 0; mx < mcux; mx++) {
                         if (!maybe_restart()) return fail(CANNY_FRAMES_ERR_FORMAT, "missing restart marker (truncated or damaged file)");
                         for (Component *c : in_scan) {
@@ -502,6 +512,7 @@ struct Decoder {
                                 }
                         }
                     }
+                }
                 luma_done = luma_done || has_luma;
             }
             if (br.overrun())

@@ -64,7 +64,9 @@ static bool read_frame(const string &path, vector<unsigned char> &px, int &heigh
     f.read((char *)magic, 2);
     if (f.gcount() == 2 && magic[0] == 0xFF && magic[1] == 0xD8) {
         f.seekg(0, ios::end);
-        vector<unsigned char> file((size_t)f.tellg());
+        const streamoff len = f.tellg();
+        if (len < 2) return false; // tellg() failed (-1: a pipe, a directory) or nothing behind the magic
+        vector<unsigned char> file((size_t)len);
         f.seekg(0);
         f.read((char *)file.data(), (streamsize)file.size());
         int st = canny_frames_jpeg_info(file.data(), file.size(), &height, &width);
@@ -176,6 +178,9 @@ static int run_batch(const string &dir, const string &outdir, float sigma, int m
 
 int main(int argc, char *argv[])
 {
+    // The batch pipeline wants its upload, compute and download streams on separate hardware queues; HIP reads this
+    // when its runtime initialises (first HIP call, below), and the library leaves the environment alone.
+    setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
     float sigma;
     int minVal;
     int maxVal;

@@ -38,3 +38,61 @@ def max_over_ranks(seconds: float, device=None) -> float:
 def aggregate_throughput(units_per_rank: int, world: int, seconds_max: float) -> float:
     """Whole-job units per second: every rank processed ``units_per_rank`` in ``seconds_max``."""
     return world * units_per_rank / seconds_max
+
+
+# ---- per-rank reporting of the host->host legs (bench.py, N ranks) -------------------------------------------------
+def gather_rows(row: dict) -> list:
+    """One row per rank, in rank order, on every rank (identity list when the process group is not initialised)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [row]
+    rows = [None] * dist.get_world_size()
+    dist.all_gather_object(rows, row)
+    return rows
+
+
+def numa_nodes_of(arr):
+    """NUMA node(s) the pages of a host array live on, from /proc/self/numa_maps ({node: pages}); None if unknown."""
+    try:
+        addr = arr.ctypes.data
+        best = None
+        with open("/proc/self/numa_maps") as f:
+            for line in f:
+                parts = line.split()
+                start = int(parts[0], 16)
+                if start <= addr and (best is None or start > best[0]):
+                    best = (start, parts)
+        if best is None:
+            return None
+        nodes = {}
+        for tok in best[1][1:]:
+            if tok.startswith("N") and "=" in tok:
+                k, _, v = tok[1:].partition("=")
+                nodes[int(k)] = int(v)
+        return nodes or None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def h2h_rank_row(rank: int, pixels: int, out_bytes: int, seconds: float, src=None, out=None) -> dict:
+    """This rank's row of a host->host batch: its own median call (not the MAX), its link rates in each direction
+    (one byte per pixel goes up, out_bytes come down) and where its pinned buffers live."""
+    return {"rank": rank, "ms_per_batch": round(seconds * 1e3, 3), "Mpixels_per_s": round(pixels / seconds / 1e6, 1),
+            "h2d_GBps": round(pixels / seconds / 1e9, 2), "d2h_GBps": round(out_bytes / seconds / 1e9, 2),
+            "pinned_src_numa_pages": numa_nodes_of(src) if src is not None else None,
+            "pinned_out_numa_pages": numa_nodes_of(out) if out is not None else None,
+            "cpus_bound": len(os.sched_getaffinity(0))}
+
+
+def config5_result(frames_per_round: int, rounds: int, pixels_per_round: int, rank: int, world: int,
+                   seconds_own: float, seconds_max: float) -> dict:
+    """BASELINE config 5's per-GPU share through the host pipeline: `rounds` batches of `frames_per_round` frames per
+    GPU re-using the same pinned buffers; weak scaling (every rank moves the same number of frames), aggregate over
+    the MAX-over-ranks time, one row per rank beside it."""
+    return {"what": f"{rounds} x {frames_per_round} = {rounds * frames_per_round} 4K frames per GPU, pinned host u8 in -> "
+                    "pinned host s16 maps out, buffers re-used per round (BASELINE.json configs[4]: 1024 per GPU)",
+            "frames_per_gpu": rounds * frames_per_round,
+            "value": round(aggregate_throughput(pixels_per_round * rounds, world, seconds_max) / 1e6, 1),
+            "unit": "Mpixels/s", "seconds": round(seconds_max, 4),
+            "per_rank": gather_rows({"rank": rank, "seconds": round(seconds_own, 4),
+                                     "Mpixels_per_s": round(pixels_per_round * rounds / seconds_own / 1e6, 1)})}

@@ -125,7 +125,9 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *                    high-priority stream beside the next call's Gaussian instead of in order before it
  *                    (no gain on 128 x 4K batches, kept for A/B)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
- *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide)
+ *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide; the packed-i16 kernel only)
+ *   "tune_sobel_variant": 0 (default) the f32 marching arithmetic (4 waves per SIMD), 1 round 2's packed-i16
+ *       arithmetic (3 waves per SIMD) -- same results bit for bit; process-wide, A/B and cross-checks
  *   "tune_plane_stores": 0 (default) the fused Sobel+NMS kernel parks a segment's plane bytes in LDS and writes
  *                    them as whole words after its last row, 1 direct byte stores (process-wide)
  *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel with the row-pass product table in LDS,
@@ -140,8 +142,10 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value);
 int canny_hip_synchronize(canny_hip_ctx *ctx);
 /* Text of the last HIP runtime error seen by this context ("" if none). */
 const char *canny_hip_last_error(const canny_hip_ctx *ctx);
-/* Number of propagate launches that did work in the last hysteresis call (diagnostic). */
-int canny_hip_last_hysteresis_iterations(const canny_hip_ctx *ctx);
+/* Number of propagation sweeps that did work in the last hysteresis / canny call (diagnostic).  After a call that only
+ * queued its kernels (see canny_hip_dev_canny) the count still lives on the device: the getter then copies it out and
+ * SYNCHRONISES the context's stream, hence the non-const context. */
+int canny_hip_last_hysteresis_iterations(canny_hip_ctx *ctx);
 
 /* ---- device / pinned memory helpers (for hosts without their own HIP allocator) ----------- */
 int canny_hip_malloc(canny_hip_ctx *ctx, void **dev_ptr, size_t bytes);
@@ -202,7 +206,7 @@ int canny_hip_canny_batch_bits(canny_hip_ctx *ctx, const unsigned char *imgs, in
  * (pipelines, streams, staging) are created on first use and kept until canny_hip_multi_gpu_release(); each
  * shard's threads are bound to the CPUs local to its GPU (sysfs local_cpulist) for the duration of the call.
  * One sharded call runs at a time per process.  Pinned caller buffers are DMA'd in place (allocate them on
- * the right NUMA node for best results); pageable ones are staged by 4 pipeline threads per GPU. */
+ * the right NUMA node for best results); pageable ones are staged by six single-stream pipelines per GPU. */
 int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
                               int height, int width, short *edges, int n_devices);
 int canny_hip_canny_multi_gpu_u8(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
@@ -246,14 +250,21 @@ int canny_hip_dev_sobel_nms_u8in(canny_hip_ctx *ctx, const unsigned char *d_smoo
 /* In place.  Blocks the host until propagation has converged (it polls a device flag). */
 int canny_hip_dev_hysteresis(canny_hip_ctx *ctx, short *d_edge_candidates, int height, int width, int n_frames,
                              int min_val, int max_val);
-/* gaussian -> fused sobel+nms -> hysteresis over n_frames resident frames. */
+/* gaussian -> fused sobel+nms -> hysteresis over n_frames resident frames.
+ * COMPLETION CONTRACT: d_edges is complete IN STREAM ORDER on the context's stream when the call has returned (work
+ * queued on that stream afterwards sees the final map) and HOST-VISIBLE after canny_hip_synchronize() -- whatever path
+ * ran.  Whether the call itself blocks the host depends on the shape: frames of <= 4096 hysteresis tiles (64x64 px)
+ * with width % 8 == 0, min_val >= 1 and the option hysteresis_tail = 1 (default) only QUEUE their five kernels and
+ * return; every other shape polls the propagation's convergence flag and returns when it has converged.  The context's
+ * stream is non-blocking with respect to the legacy default stream: a hipMemcpy on the default stream does NOT wait for
+ * it -- copy with canny_hip_memcpy_d2h (same stream), or synchronize first. */
 int canny_hip_dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int min_val, int max_val,
                         int height, int width, int n_frames, short *d_edges);
 /* canny() for a STREAM of batches -- the reference's capture loop (src/main.cpp:120-137: canny() on one frame
  * after the other) with resident batches in place of frames.  Same results as canny_hip_dev_canny, but the call
- * returns with the batch's hysteresis sweeps still queued: the host round trip that tells a plain call whether the
- * sweeps converged (and idles the GPU for ~20 us) happens in the next call, after that call has queued its
- * Gaussian.  d_edges of call i
+ * ALWAYS returns with the batch's hysteresis sweeps still queued, also for the shapes whose plain call has to poll the
+ * convergence flag (large frames, hysteresis_tail = 0): that host round trip (which idles the GPU for ~20 us) happens
+ * in the next call, after that call has queued its Gaussian.  d_edges of call i
  * is complete -- for work queued on the context's stream and, after a synchronize, for the host -- once call i+1
  * or canny_hip_dev_canny_stream_flush() has returned; until then the caller must neither read nor free it.
  * d_img may be reused as soon as the context's stream has passed the call.  Every other compute entry point of
@@ -281,6 +292,14 @@ int canny_hip_profile_get(canny_hip_ctx *ctx, int stage, double *total_ms, long 
 /* Runs the DEVICE magnitude / angle-bin functions over every (gx,gy) in [-lim,lim]^2 and writes
  * tables indexed [gy+lim][gx+lim] to host memory. */
 int canny_hip_selftest_mag_angle(canny_hip_ctx *ctx, int lim, short *magnitudes, unsigned char *bins);
+/* Measurement aid (bench.py): a plain device copy of nbytes (a multiple of 16; both pointers 16-byte aligned), launched
+ * `launches` times on the context's stream; *avg_ms receives the average device time of one launch (HIP events attached
+ * to the dispatch).  It calibrates what a 1:1 read/write stream reaches on THIS device beside the Sobel+NMS pass, whose
+ * roofline is quoted against the 8 TB/s spec (the reference has no counterpart: src/cuda.cu:83-101 only ever copies
+ * host<->device).  Synchronous. */
+int canny_hip_probe_copy(canny_hip_ctx *ctx, const void *d_src, void *d_dst, size_t nbytes, int launches,
+                         double *avg_ms);
+
 /* Compares the Gaussian kernels' reciprocal-based division a/divisor with the IEEE divide for EVERY
  * float a in [0, 256] (1.13e9 values) on the device; *mismatches receives the number of differences and
  * *largest_mismatching_dividend the largest a that differed (0 if none). */

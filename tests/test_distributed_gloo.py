@@ -69,3 +69,55 @@ def test_rank_sharding_and_max_timing(n_frames, world, range0):
     sizes = [e - b for b, e in ranges]
     assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
     assert sharding.aggregate_throughput(10, 2, 4.0) == 5.0
+
+
+def _report_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        src = np.zeros((2, H, W), np.uint8)
+        out = np.zeros((2, H, W), np.int16)
+        seconds = 0.010 * (1 + rank)                          # rank 1 pretends to be slower
+        rows = sharding.gather_rows(sharding.h2h_rank_row(rank, src.size, out.nbytes, seconds, src, out))
+        t_max = sharding.max_over_ranks(seconds)
+        c5 = sharding.config5_result(frames_per_round=2, rounds=8, pixels_per_round=src.size, rank=rank, world=world,
+                                     seconds_own=8 * seconds, seconds_max=8 * t_max)
+        if rank == 0:
+            out_q.put((rows, c5, t_max))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_per_rank_rows_and_config5_at_world_2():
+    """The N-rank bench line (bench.py host_to_host): one row per rank in rank order with that rank's OWN time, link
+    rates and buffer placement, and config 5 (1024 frames per GPU as 8 rounds) aggregated over the MAX time."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_report_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rows, c5, t_max = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    px = 2 * H * W
+    assert [r["rank"] for r in rows] == [0, 1]
+    for r in rows:
+        assert set(r) >= {"rank", "ms_per_batch", "Mpixels_per_s", "h2d_GBps", "d2h_GBps", "pinned_src_numa_pages",
+                          "pinned_out_numa_pages", "cpus_bound"}
+        assert r["ms_per_batch"] == 10.0 * (1 + r["rank"])            # its own time, not the MAX
+        assert r["d2h_GBps"] == round(2 * r["h2d_GBps"], 2) or abs(r["d2h_GBps"] - 2 * r["h2d_GBps"]) < 0.02
+        assert r["cpus_bound"] >= 1
+        assert r["pinned_src_numa_pages"] is None or all(v > 0 for v in r["pinned_src_numa_pages"].values())
+    assert t_max == 0.020
+    assert c5["frames_per_gpu"] == 16 and c5["unit"] == "Mpixels/s"
+    assert [r["rank"] for r in c5["per_rank"]] == [0, 1]
+    assert c5["seconds"] == round(8 * t_max, 4)
+    assert c5["value"] == round(world * 8 * px / (8 * t_max) / 1e6, 1)    # aggregate over the MAX-over-ranks time
+    assert c5["per_rank"][1]["seconds"] == 2 * c5["per_rank"][0]["seconds"]
+    # single process: the helpers degrade to one row
+    solo = sharding.gather_rows({"rank": 0})
+    assert solo == [{"rank": 0}]

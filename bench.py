@@ -428,12 +428,22 @@ def main():
         return r
 
     fused = stages["hyst_classify"]["launch_groups"] == 0  # canny() ran Sobel+NMS with the classify step inside
+    u8_plane = bool(ctx.get_option("last_canny_smoothed_u8"))  # the smoothed plane between the two kernels was bytes
     sn_ms, sn_n = sn_ms_total, sn_launches  # the launches of the timed region that carried events
-    if fused:
-        # The pass the pipeline actually runs: s16 smoothed in (2 B/px); out: the provisional s16 edge map
-        # (2 B/px, completed in place by the propagation sweeps -- there is no finalize pass) and the two 1-bit
-        # hysteresis planes (2/8 B/px).  `frac` / `achieved` price it at SURVEY.md 8(d)'s 4 B/px -- the figure the
-        # target is stated in --; `frac_own_bytes` at the 4.25 B/px it really moves.
+    if fused and u8_plane:
+        # Round 3 default: the Gaussian hands the fused kernel a u8 plane ((short)(sum/count) lies in [0,255],
+        # src/utils.cpp:62).  The kernel of the timed region then moves 1 B/px in + 2 B/px provisional s16 edge map +
+        # 2/8 B/px bit-planes out = 3.25 B/px, and is priced with THOSE bytes; the 4 B/px pass SURVEY.md 8(d) prices
+        # (s16 in, s16 out) and the fused s16-input form are timed right after the region, below.
+        roofline = roof("sobel_nms_classify_u8in",
+                        "fused Sobel+NMS+threshold-classify on the u8 smoothed plane (u8 in; s16 edge map + "
+                        "strong/connectable bit-planes out) -- what canny() runs", 3.25, sn_ms, sn_n,
+                        {"limiter": "VALU issue (~35 instructions per pixel) beside an HBM stream that a plain copy "
+                                    "moves 1.3-1.5x faster (copy_probe), see DESIGN.md"})
+    elif fused:
+        # s16 smoothed in (2 B/px); out: the provisional s16 edge map (2 B/px, completed in place by the propagation
+        # sweeps -- there is no finalize pass) and the two 1-bit hysteresis planes (2/8 B/px).  `frac` / `achieved`
+        # price it at SURVEY.md 8(d)'s 4 B/px; `frac_own_bytes` at the 4.25 B/px it really moves.
         roofline = roof("sobel_nms_classify",
                         "fused Sobel+NMS+threshold-classify (s16 smoothed in; s16 edge map + strong/connectable "
                         "bit-planes out), priced at SURVEY 8(d)'s 4 B/px", 4.0, sn_ms, sn_n,
@@ -472,12 +482,38 @@ def main():
     roofline["copy_probe"] = copy_probe
     roofline["time_over_copy"] = round(roofline["avg_launch_ms"] / copy_ms, 3) if copy_ms > 0 else None
     del d_sm
+    # The fused kernel in its s16-INPUT form (canny() with the option smoothed_u8 = 0: the pass whose bytes are
+    # SURVEY 8(d)'s 4 B/px plus the bit-planes), same batch, same events, right after the region.
+    roofline_fused_s16in = None
+    if fused and u8_plane:
+        ctx.set_option("smoothed_u8", 0)
+        ctx.set_option("profile_stage_mask", 1 << capi.STAGE_SOBEL_NMS)
+        plain_step()
+        torch.cuda.synchronize()
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for _ in range(args.steps):
+            plain_step()
+        torch.cuda.synchronize()
+        msf, nf = ctx.profile_get(capi.STAGE_SOBEL_NMS)
+        ctx.profile_enable(False)
+        ctx.set_option("profile_stage_mask", 0)
+        ctx.set_option("smoothed_u8", 1)
+        roofline_fused_s16in = roof("sobel_nms_classify", "fused Sobel+NMS+threshold-classify on the s16 smoothed plane "
+                                    "(canny() with smoothed_u8 = 0), priced at SURVEY 8(d)'s 4 B/px", 4.0, msf, nf,
+                                    {"timed": "after the timed region, same batch, HIP events on every launch"})
+        own = roof("sobel_nms_classify", "", 4.25, msf, nf)
+        roofline_fused_s16in["frac_own_bytes"] = own["frac"]
+        roofline_fused_s16in["own_bytes_per_px"] = 4.25
+        roofline_fused_s16in["time_over_copy"] = round(roofline_fused_s16in["avg_launch_ms"] / copy_ms, 3) if copy_ms > 0 else None
     roofline_s16 = roof("sobel_nms", "fused Sobel+NMS, stage-API form (s16 smoothed in, s16 suppressed magnitude out)",
                         4.0, ms16, n16, {"timed": "after the timed region, same batch, HIP events"})
     roofline_s16["time_over_copy"] = round(roofline_s16["avg_launch_ms"] / copy_ms, 3) if copy_ms > 0 else None
 
     per_kernel = {
-        "gaussian": roof("gaussian", "separable Gaussian, rows+columns in one kernel (u8 in, s16 out)", 3.0,
+        "gaussian": roof("gaussian_u8out" if u8_plane else "gaussian",
+                         "separable Gaussian, rows+columns in one kernel (u8 in, %s out)" % ("u8" if u8_plane else "s16"),
+                         2.0 if u8_plane else 3.0,
                          stages["gaussian"]["ms_per_step"] * args.steps, stages["gaussian"]["launch_groups"],
                          {"limiter": "VALU issue: separately rounded f32 mul/add chains (bit-exactness)"}),
     }
@@ -535,6 +571,7 @@ def main():
         "host_to_host": h2h,
         "roofline": roofline,
         "roofline_sobel_nms_s16": roofline_s16,
+        "roofline_sobel_nms_classify_s16in": roofline_fused_s16in,
         "roofline_other_kernels": per_kernel,
         "stages": stages,
         "plain_calls": plain,

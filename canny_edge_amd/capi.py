@@ -48,7 +48,7 @@ EXPORTS = (
     "canny_hip_multi_gpu_release", "canny_hip_device_local_cpus", "canny_hip_selftest_cpulist_count",
     "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in", "canny_hip_host_register", "canny_hip_host_unregister",
     "canny_hip_canny_batch_bits", "canny_hip_canny_multi_gpu_bits", "canny_hip_dev_canny_bits",
-    "canny_hip_probe_copy",
+    "canny_hip_probe_copy", "canny_hip_ctx_get_option",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -133,6 +133,7 @@ def load() -> C.CDLL:
         "canny_hip_profile_reset": ([p], i),
         "canny_hip_profile_get": ([p, i, C.POINTER(C.c_double), C.POINTER(C.c_long)], i),
         "canny_hip_probe_copy": ([p, p, p, C.c_size_t, i, C.POINTER(C.c_double)], i),
+        "canny_hip_ctx_get_option": ([p, C.c_char_p, ip], i),
         "canny_hip_selftest_mag_angle": ([p, i, p, p], i),
         "canny_hip_selftest_div": ([p, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
         "canny_hip_selftest_div_fma": ([p, f, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
@@ -237,6 +238,11 @@ class Context:
     def set_option(self, name: str, value: int):
         """Kernel-path selection ("gaussian_path" / "sobel_nms_path": 0 auto, 1 baseline, 2 wave-marching)."""
         self._check(self._L.canny_hip_ctx_set_option(self._h, name.encode(), value), f"set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        self._check(self._L.canny_hip_ctx_get_option(self._h, name.encode(), C.byref(v)), f"get_option({name})")
+        return v.value
 
     def synchronize(self):
         self._check(self._L.canny_hip_synchronize(self._h), "synchronize")

@@ -184,7 +184,8 @@ struct canny_hip_ctx {
     int fuse_classify = 1;   // canny(): Sobel+NMS emits the hysteresis bit-planes directly when it can
     // canny(): the smoothed plane between the Gaussian and the fused Sobel+NMS kernel as bytes (its values lie in
     // [0,255], src/utils.cpp:62): 0 = s16 plane, 1 = u8 plane
-    int smoothed_u8 = 0;
+    int smoothed_u8 = 1; // canny(): the plane between the Gaussian and the fused Sobel+NMS as bytes (round 3 default)
+    int last_canny_u8 = 0; // whether the last canny call really used it (window, taps and shape permitting)
     // canny(): after the two batch-wide sweeps, one launch with a workgroup per frame finishes the propagation
     // (launch_hyst_tail): no further launches, no host round trip, the call returns without waiting.
     // 1 (default) = for frames of up to kTailMaxTiles tiles, 0 = never (the multi-launch scheme with its poll)
@@ -579,6 +580,7 @@ int dev_canny(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int l
         if ((rc = make_taps(sigma, taps))) return rc;
         if (gaussian_u8_possible(ctx, taps, h, w)) sm_u8 = ctx->smoothed_u8;
     }
+    ctx->last_canny_u8 = sm_u8;
     if ((rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm, sm_u8))) return rc;
     // Sobel+NMS+classify on the s16 or the u8 smoothed plane
     auto fused_sobel = [&](const short *smp, short *edges, uint64_t *S, uint64_t *C, const HystGeom &gg, int ev,
@@ -713,6 +715,7 @@ int dev_canny_stream(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma
         if (rt) return rt;
         if (gaussian_u8_possible(ctx, taps, h, w)) sm_u8 = ctx->smoothed_u8;
     }
+    ctx->last_canny_u8 = sm_u8;
     int rc = dev_gaussian(ctx, d_img, sigma, h, w, n, sm, sm_u8);
     if (rc) return rc;
     if ((rc = finish_pending(ctx))) return rc; // host waits here while the Gaussian runs
@@ -920,6 +923,19 @@ int canny_hip_ctx_set_stream(canny_hip_ctx *ctx, void *hip_stream)
 
 int canny_hip_ctx_device(const canny_hip_ctx *ctx) { return ctx ? ctx->device : -1; }
 
+int canny_hip_ctx_get_option(const canny_hip_ctx *ctx, const char *name, int *value)
+{
+    if (!ctx || !name || !value) return CANNY_HIP_ERR_INVALID;
+    if (!std::strcmp(name, "smoothed_u8")) *value = ctx->smoothed_u8;
+    else if (!std::strcmp(name, "last_canny_smoothed_u8")) *value = ctx->last_canny_u8; // read-only
+    else if (!std::strcmp(name, "fuse_classify")) *value = ctx->fuse_classify;
+    else if (!std::strcmp(name, "hysteresis_tail")) *value = ctx->hyst_tail;
+    else if (!std::strcmp(name, "gaussian_path")) *value = ctx->gaussian_path;
+    else if (!std::strcmp(name, "sobel_nms_path")) *value = ctx->sobel_nms_path;
+    else return CANNY_HIP_ERR_INVALID;
+    return CANNY_HIP_OK;
+}
+
 int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name || value < 0) return CANNY_HIP_ERR_INVALID;
@@ -944,7 +960,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
         for (auto &n : ctx->prof_seen) n = 0;
     } else if (!std::strcmp(name, "profile_stage_mask")) ctx->prof_mask = value ? (unsigned)value : ~0u;
     else if (!std::strcmp(name, "tune_sobel_px") && value <= 1) sobel_nms_set_px_variant(value); // process-wide
-    else if (!std::strcmp(name, "tune_sobel_variant") && value <= 1) sobel_nms_set_arith_variant(value); // process-wide
+    else if (!std::strcmp(name, "tune_sobel_variant") && value <= 2) sobel_nms_set_arith_variant(value); // process-wide
     else if (!std::strcmp(name, "tune_plane_stores") && value <= 1) sobel_nms_set_plane_store_variant(value); // process-wide
     else if (!std::strcmp(name, "gaussian_fma_div") && value <= 1) gaussian_set_fma_div(value != 0); // process-wide
     else if (!std::strcmp(name, "tune_finalize_mode") && value <= 1) hyst_set_finalize_mode(value);   // process-wide

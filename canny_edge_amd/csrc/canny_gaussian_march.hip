@@ -771,6 +771,39 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
            (long long)n_frames * n_strips * ((height + seg_for(target) - 1) / seg_for(target)) < 2048)
         target >>= 1;
     int seg = seg_for(tune_seg_target >= 8 ? tune_seg_target : target);
+    // Batches that fill the chip several times over: the waves of a launch run in "rounds" of as many waves as the
+    // chip holds (all waves do the same amount of work), and the last round costs a whole round however few waves are
+    // left for it.  Pick the segment length that minimises rounds x rows per wave (halo rows included) -- e.g.
+    // 128 x 4K at window 11: 144-row segments are 15 per frame = 30720 waves = exactly 6 rounds of 5120, where the
+    // 133-row default of the rule above needs 7 rounds (17 segments per frame, the last one 32 rows): 1.069 -> 1.032 ms
+    // (profiles/r03/ab4_segments_whole_rounds.txt; 166 rows: 1.120, 100 rows: 1.050, as the model ranks them).
+    if (symmetric && tune_seg_target < 8) {
+        static int n_simds = 0; // SIMDs of the device (4 per CU); one device family, so one value per process
+        if (n_simds == 0) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+            n_simds = 4 * cus;
+        }
+        // waves per SIMD the kernel's registers allow (gauss_sym_kernel<C, true>: 38/49/68/76/95/105/125/128 VGPRs)
+        static const int kWavesPerSimd[9] = {0, 8, 8, 7, 6, 5, 4, 4, 4};
+        const long long slots = (long long)n_simds * kWavesPerSimd[C];
+        const long long frames_strips = (long long)n_frames * n_strips;
+        if (frames_strips * ((height + seg - 1) / seg) >= 2 * slots) {
+            long long best_cost = -1;
+            for (int m = 4; m * K::RING - 2 * C <= 400; m++) {
+                const int s_rows = m * K::RING - 2 * C;
+                if (s_rows < 48) continue;
+                const long long w = frames_strips * ((height + s_rows - 1) / s_rows);
+                const long long cost = ((w + slots - 1) / slots) * (long long)(s_rows + 2 * C);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    seg = s_rows;
+                }
+            }
+        }
+    }
     int n_segs = (height + seg - 1) / seg;
     long long waves = (long long)n_frames * n_strips * n_segs;
     if (waves > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -81,7 +81,7 @@ hipError_t launch_sobel_nms(const int16_t *smoothed, int16_t *out, int height, i
 // Fused Sobel+NMS, wave-marching and LDS-free (canny_sobel_nms_march.hip); smoothed must lie in [0,255].
 bool sobel_nms_march_supported(int height, int width);
 void sobel_nms_set_px_variant(int v); // A/B: 0 = 8 pixels per lane, 1 = 4 pixels per lane (more resident waves)
-void sobel_nms_set_arith_variant(int v); // A/B: 0 = f32 marching arithmetic (default), 1 = round 2's packed-i16 kernel
+void sobel_nms_set_arith_variant(int v); // 0 = automatic (f32 for the fused classify kernel, packed-i16 for s16 -> s16), 1 = packed-i16, 2 = f32
 // A/B (fused kernel): 0 = plane bytes staged in LDS for 8 rows and written as 8-byte words, 1 = direct byte stores
 void sobel_nms_set_plane_store_variant(int v);
 // An event pair attached to one kernel dispatch (hipExtLaunchKernel): that kernel's begin and end timestamps.

@@ -924,7 +924,11 @@ bool sobel_nms_march_supported(int height, int width) { return height >= 2 && wi
 
 static int px_variant = 0; // A/B switch "tune_sobel_px": 0 = 8 pixels per lane, 1 = 4 pixels per lane
 void sobel_nms_set_px_variant(int v) { px_variant = v; }
-// A/B switch "tune_sobel_variant": 0 = f32 marching arithmetic (default), 1 = round 2's packed-i16 arithmetic
+// "tune_sobel_variant": 0 = automatic (default): the f32 marching arithmetic for the fused Sobel+NMS+classify kernel
+// canny() runs, round 2's packed-i16 arithmetic for the s16 -> s16 stage-API kernel -- what three interleaved A/B
+// sessions on three boxes measured (profiles/r03/ab_session_s{1,2,3}.txt: fused kernel on the u8 plane 0.87-0.90 ms
+// f32 against 0.92-0.95 packed; stage kernel 0.86-0.90 packed against 0.89-0.96 f32); 1 = packed-i16 everywhere,
+// 2 = f32 everywhere (parity tests run all of them)
 static int arith_variant = 0;
 void sobel_nms_set_arith_variant(int v) { arith_variant = v; }
 // A/B switch "tune_plane_stores": 0 = plane bytes staged in LDS and written as words, 1 = direct byte stores
@@ -965,7 +969,8 @@ static hipError_t launch_march(const void *smoothed, int16_t *out, const PlaneAr
     unsigned blocks = (unsigned)((waves + SNM_WPB - 1) / SNM_WPB);
     const PlaneArgs pl = planes ? *planes : PlaneArgs{};
     const dim3 grid(blocks), block(SNM_WPB * 64);
-    if (arith_variant == 0 && np == 4) { // the f32 arithmetic: every 8-pixel form
+    const bool use_f32 = arith_variant == 2 || (arith_variant == 0 && planes != nullptr);
+    if (use_f32 && np == 4) { // the f32 arithmetic: every 8-pixel form
         const bool lds = planes && plane_store_variant == 0;
 #define CANNY_FLT_LAUNCH(P, L, U)                                                                                      \
     launch_timed(sobel_nms_march_kernel<P, 4, L, U, true>, grid, block, stream, ev, smoothed, out, height, width,      \

@@ -52,23 +52,30 @@ def gather_rows(row: dict) -> list:
 
 
 def numa_nodes_of(arr):
-    """NUMA node(s) the pages of a host array live on, from /proc/self/numa_maps ({node: pages}); None if unknown."""
+    """NUMA node(s) the pages of a host array live on: {node: resident pages}, summed over every mapping of
+    /proc/self/maps that overlaps the array (the kernel splits a big allocation into several mappings when parts of
+    it get different flags) with the per-node counts of /proc/self/numa_maps; huge pages count as one page each.
+    None if unknown."""
     try:
-        addr = arr.ctypes.data
-        best = None
+        lo_a, hi_a = arr.ctypes.data, arr.ctypes.data + max(1, arr.nbytes)
+        starts = set()
+        with open("/proc/self/maps") as f:
+            for line in f:
+                lo, _, hi = line.split()[0].partition("-")
+                if int(lo, 16) < hi_a and int(hi, 16) > lo_a:
+                    starts.add(int(lo, 16))
+        if not starts:
+            return None
+        nodes = {}
         with open("/proc/self/numa_maps") as f:
             for line in f:
                 parts = line.split()
-                start = int(parts[0], 16)
-                if start <= addr and (best is None or start > best[0]):
-                    best = (start, parts)
-        if best is None:
-            return None
-        nodes = {}
-        for tok in best[1][1:]:
-            if tok.startswith("N") and "=" in tok:
-                k, _, v = tok[1:].partition("=")
-                nodes[int(k)] = int(v)
+                if int(parts[0], 16) not in starts:
+                    continue
+                for tok in parts[1:]:
+                    k, _, v = tok[1:].partition("=")
+                    if tok.startswith("N") and k.isdigit() and v.isdigit():
+                        nodes[int(k)] = nodes.get(int(k), 0) + int(v)
         return nodes or None
     except (OSError, ValueError, IndexError):
         return None

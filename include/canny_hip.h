@@ -98,7 +98,7 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "gaussian_fma_div": 1 (default) / 0 -- single-fma division by the full-window weight (process-wide)
  *   "fuse_classify": 1 (default) / 0 -- canny(): the Sobel+NMS kernel writes the hysteresis bit-planes itself
  *                    (used when width % 8 == 0 and min_val >= 1; otherwise the separate kernels run)
- *   "smoothed_u8": 0 (default) / 1 -- canny(): the smoothed plane between the Gaussian and the fused Sobel+NMS
+ *   "smoothed_u8": 1 (default since round 3) / 0 -- canny(): the smoothed plane between the Gaussian and the fused Sobel+NMS
  *                    kernel is stored as bytes instead of shorts ((short)(sum/count) lies in [0,255],
  *                    src/utils.cpp:62): 5.25 instead of 7.25 algorithmic bytes per pixel through HBM.
  *                    Used when the fused path and the marching Gaussian apply, else ignored.
@@ -126,8 +126,9 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *                    (no gain on 128 x 4K batches, kept for A/B)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
  *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide; the packed-i16 kernel only)
- *   "tune_sobel_variant": 0 (default) the f32 marching arithmetic (4 waves per SIMD), 1 round 2's packed-i16
- *       arithmetic (3 waves per SIMD) -- same results bit for bit; process-wide, A/B and cross-checks
+ *   "tune_sobel_variant": 0 (default) automatic -- the f32 marching arithmetic (4 waves per SIMD) for the fused
+ *       Sobel+NMS+classify kernel of canny(), round 2's packed-i16 arithmetic (3 waves per SIMD) for the s16 -> s16
+ *       stage kernel --, 1 packed-i16 everywhere, 2 f32 everywhere; same results bit for bit; process-wide
  *   "tune_plane_stores": 0 (default) the fused Sobel+NMS kernel parks a segment's plane bytes in LDS and writes
  *                    them as whole words after its last row, 1 direct byte stores (process-wide)
  *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel with the row-pass product table in LDS,
@@ -139,6 +140,11 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *                    region that needs one kernel's duration enables that stage only.
  *   "profile_sample_interval": N >= 1 (default 1): only every N-th launch group of a stage gets its event pair */
 int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value);
+/* Reads back "smoothed_u8", "fuse_classify", "hysteresis_tail", "gaussian_path", "sobel_nms_path", and the read-only
+ * "last_canny_smoothed_u8": 1 if the context's last canny call really ran on the u8 smoothed plane (the option is a
+ * request: windows beyond 17, asymmetric taps and shapes the fused kernel does not take fall back to the s16 plane).
+ * bench.py uses it to price the kernel it timed with the bytes that kernel moved. */
+int canny_hip_ctx_get_option(const canny_hip_ctx *ctx, const char *name, int *value);
 int canny_hip_synchronize(canny_hip_ctx *ctx);
 /* Text of the last HIP runtime error seen by this context ("" if none). */
 const char *canny_hip_last_error(const canny_hip_ctx *ctx);

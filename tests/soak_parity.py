@@ -85,7 +85,7 @@ def main():
         frames = np.stack([picture(rng, kind, h, w) for _ in range(n)])
         want = list(pool.map(lambda f: oracle.canny(f, sigma, lo, hi), frames))
         opts = {"hysteresis_tail": int(rng.integers(0, 2)) if rng.random() < 0.3 else 1,
-                "smoothed_u8": int(rng.random() < 0.25),
+                "smoothed_u8": int(rng.random() < 0.6),
                 "tune_batch_chunk_frames": int(rng.integers(0, 4)),
                 "tune_batch_pipe_mode": int(rng.integers(0, 3)),
                 "tune_batch_workers": int(rng.integers(0, 4))}

@@ -436,16 +436,22 @@ def test_gaussian_half_windows_covered():
     assert centers == list(range(1, 9)), centers
 
 
-@pytest.fixture(params=[(0, 0), (1, 0), (0, 1)], ids=["8px_per_lane", "4px_per_lane", "8px_direct_plane_stores"])
+@pytest.fixture(params=[(0, 0, 0), (2, 0, 0), (1, 0, 0), (1, 1, 0), (2, 0, 1), (1, 0, 1)],
+                ids=["auto", "f32_everywhere", "packed_i16_everywhere", "packed_i16_4px_per_lane",
+                     "f32_direct_plane_stores", "packed_i16_direct_plane_stores"])
 def sobel_px(hip, request):
-    """Runs a test once per variant of the marching Sobel+NMS kernel (process-wide A/B switches): pixels per
-    lane, and whether the fused kernel stages its plane bytes in LDS (default) or stores them directly."""
-    px, direct = request.param
+    """Runs a test once per variant of the marching Sobel+NMS kernel (process-wide switches): the arithmetic (automatic
+    = f32 for the fused classify kernel and packed i16 for the s16 -> s16 kernel, or either one everywhere), pixels per
+    lane (packed i16 only), and whether the fused kernel stages its plane bytes in LDS (default) or stores them
+    directly."""
+    variant, px, direct = request.param
     with hip.Context(0) as c:
+        c.set_option("tune_sobel_variant", variant)
         c.set_option("tune_sobel_px", px)
         c.set_option("tune_plane_stores", direct)
     yield request.param
     with hip.Context(0) as c:
+        c.set_option("tune_sobel_variant", 0)
         c.set_option("tune_sobel_px", 0)
         c.set_option("tune_plane_stores", 0)
 
@@ -481,11 +487,13 @@ FUSE_SHAPES = [(2, 8), (3, 16), (64, 64), (65, 72), (130, 496), (100, 504), (63,
 FUSE_THRESHOLDS = [(50, 150), (1, 1), (1, 5000), (100, 50), (20, 20), (255, 256), (0, 100), (300, 2000)]
 
 
+@pytest.mark.parametrize("plane", [1, 0], ids=["u8_smoothed_plane", "s16_smoothed_plane"])
 @pytest.mark.parametrize("fuse", [0, 1])
 @pytest.mark.parametrize("lo,hi", FUSE_THRESHOLDS)
-def test_canny_fused_classify(hip, fuse, lo, hi, sobel_px):
+def test_canny_fused_classify(hip, fuse, lo, hi, sobel_px, plane):
     with hip.Context(0) as c:
         c.set_option("fuse_classify", fuse)
+        c.set_option("smoothed_u8", plane)  # 1 = the default: bytes between the Gaussian and the fused kernel
         for h, w in FUSE_SHAPES:
             for n, seed in ((1, 3), (3, 4)):
                 frames = np.stack([_mixed(h, w, seed + 10 * i) if i != 1 else _noise(h, w, seed) for i in range(n)])

@@ -68,7 +68,7 @@ def test_sobel_nms_from_u8_plane_equals_oracle(hip):
             assert np.array_equal(got, want), (h, w)
 
 
-@pytest.mark.parametrize("mode", [1])
+@pytest.mark.parametrize("mode", [1, 0], ids=["u8_plane_default", "s16_plane"])
 @pytest.mark.parametrize("lo,hi", [(50, 150), (1, 1), (100, 50), (0, 100), (255, 256)])
 def test_canny_with_u8_smoothed_plane(hip, mode, lo, hi):
     """Shapes with width % 8 != 0 and min_val = 0 do not take the fused path: the option must then be ignored."""
@@ -91,7 +91,7 @@ def test_canny_with_u8_smoothed_plane(hip, mode, lo, hi):
                 assert np.array_equal(got, want), (mode, lo, hi, h, w, sigma)
 
 
-@pytest.mark.parametrize("mode", [1])
+@pytest.mark.parametrize("mode", [1, 0], ids=["u8_plane_default", "s16_plane"])
 def test_canny_u8_smoothed_plane_large_windows_fall_back(hip, mode):
     """sigma 3.0 -> window 19: no marching Gaussian, so no byte plane; the result must not change."""
     img = _mixed(120, 200, 5)
@@ -101,7 +101,7 @@ def test_canny_u8_smoothed_plane_large_windows_fall_back(hip, mode):
             assert np.array_equal(c.canny(img, sigma, 30, 90), oracle.canny(img, sigma, 30, 90)), sigma
 
 
-@pytest.mark.parametrize("mode", [1])
+@pytest.mark.parametrize("mode", [1, 0], ids=["u8_plane_default", "s16_plane"])
 def test_stream_of_batches_and_host_batch_with_u8_smoothed_plane(hip, mode):
     h, w, n = 270, 480, 6
     batches = [np.stack([synth_frame(h, w, 100 * b + i) for i in range(n)]) for b in range(4)]
@@ -131,3 +131,23 @@ def test_stream_of_batches_and_host_batch_with_u8_smoothed_plane(hip, mode):
         # 4K-wide frame through the host API (many strips per row)
         big = synth_frame(96, 3840, 9)
         assert np.array_equal(c.canny(big, 1.4, 50, 150), oracle.canny(big, 1.4, 50, 150))
+
+
+def test_u8_plane_is_the_default_and_reported(hip):
+    """Round 3: canny() keeps the smoothed plane as bytes by default; "last_canny_smoothed_u8" tells which plane the last
+    call really used (bench.py prices the Sobel+NMS kernel it timed with the bytes that kernel moved)."""
+    img = _mixed(128, 200, 3)        # width % 8 == 0: fused path, marching Gaussian at sigma 1.4
+    odd = _mixed(128, 203, 4)        # width % 8 != 0: the fused kernel does not take it
+    with hip.Context(0) as c:
+        assert c.get_option("smoothed_u8") == 1
+        assert np.array_equal(c.canny(img, 1.4, 50, 150), oracle.canny(img, 1.4, 50, 150))
+        assert c.get_option("last_canny_smoothed_u8") == 1
+        assert np.array_equal(c.canny(img, 3.0, 50, 150), oracle.canny(img, 3.0, 50, 150))   # window 19
+        assert c.get_option("last_canny_smoothed_u8") == 0
+        assert np.array_equal(c.canny(odd, 1.4, 50, 150), oracle.canny(odd, 1.4, 50, 150))
+        assert c.get_option("last_canny_smoothed_u8") == 0
+        c.set_option("smoothed_u8", 0)
+        assert np.array_equal(c.canny(img, 1.4, 50, 150), oracle.canny(img, 1.4, 50, 150))
+        assert c.get_option("last_canny_smoothed_u8") == 0
+        with pytest.raises(hip.CannyHipError):
+            c.get_option("no_such_option")

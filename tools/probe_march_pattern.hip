@@ -317,7 +317,7 @@ int main(int argc, char **argv)
         g.n_strips = (W + g.sw - 1) / g.sw;
         g.xcd_remap = 1;
         char nm[128];
-        for (int seg : {64, 128}) {
+        for (int seg : {8, 16, 32, 64, 128}) {
             g.seg = seg;
             g.n_segs = (H + seg - 1) / seg;
             g.total_waves = F * g.n_strips * g.n_segs;

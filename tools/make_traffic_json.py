@@ -22,11 +22,20 @@ FRAMES, HEIGHT, WIDTH = 128, 2160, 3840  # bench.py's default workload (what too
 # key in the JSON -> (substring of the rocprofv3 kernel name, algorithmic bytes per pixel, frames per launch, note)
 # (with the option overlap_hysteresis=1 canny() would launch the fused kernel once per half of the batch)
 KERNELS = {
-    "sobel_nms_classify": ("sobel_nms_march_kernel<true, 4,", 4.25, FRAMES,
+    # what canny() runs since round 3: the f32 fused kernel on the u8 smoothed plane (8 B/lane reads)
+    "sobel_nms_classify_u8in": ("sobel_nms_march_kernel<true, 4, true, true, true>", 3.25, FRAMES,
+                                "8 B/lane reads (FETCH_SIZE doubled: the counter tallies 64 B per 128 B request whatever "
+                                "the lane width -- the u8 Gaussian's 4 B/lane reads show the same half); 16 B/lane "
+                                "edge-map writes (exact) plus the plane bytes (raw WRITE_SIZE)"),
+    # the same kernel on the s16 plane (canny() with smoothed_u8 = 0; bench.py times it after the region)
+    "sobel_nms_classify": ("sobel_nms_march_kernel<true, 4, true, false, true>", 4.25, FRAMES,
                            "16 B/lane reads (FETCH_SIZE doubled); 16 B/lane edge-map writes (exact) plus the plane "
                            "bytes (raw WRITE_SIZE, 6 % of the writes)"),
-    "sobel_nms": ("sobel_nms_march_kernel<false, 4,", 4.0, FRAMES,
+    # the stage-API kernel SURVEY 8(d) prices (packed-i16 arithmetic)
+    "sobel_nms": ("sobel_nms_march_kernel<false, 4, false, false, false>", 4.0, FRAMES,
                   "16 B/lane reads (FETCH_SIZE doubled) and writes (exact)"),
+    "gaussian_u8out": ("gauss_sym_kernel<5, true, true>", 2.0, FRAMES,
+                       "4 B/lane reads (FETCH_SIZE doubled, see above) and 4 B/lane writes (raw WRITE_SIZE)"),
 }
 
 

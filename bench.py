@@ -121,8 +121,12 @@ def host_to_host(ctx, np, base_np, args, rank, world, sync_max, check):
     from canny_edge_amd import sharding
     H, W, n = args.height, args.width, args.h2h_frames
     px = n * H * W
+    compact = ctx.get_option("tune_batch_compact") == 0  # s16 / u8 maps cross the link as bit maps (round 3 default)
     res = {"frames_per_gpu": n, "height": H, "width": W, "sigma": args.sigma, "reps": args.h2h_reps,
            "pcie_peak_GBps_per_direction": PCIE_PEAK_GBS,
+           "transfer": ("compact: the finished s16 / u8 map is packed to 1 bit per pixel on the device, the bits cross "
+                        "PCIe (1/16 of the s16 map) and host threads write the caller's plane from them"
+                        if compact else "the map itself is downloaded"),
            "what": "canny_hip_canny_batch / _u8 / _bits on pinned host buffers: 3-stream chunk pipeline "
                    "(upload | kernels | download), wall time of the median of --h2h-reps calls, MAX over ranks; "
                    "s16 = the reference's short maps, u8 = the same 0/255 as bytes, bits = 1 bit per pixel"}
@@ -145,14 +149,16 @@ def host_to_host(ctx, np, base_np, args, rank, world, sync_max, check):
                 calls.append(time.perf_counter() - t0)
             t_own = sorted(calls)[len(calls) // 2]
             t = sync_max(t_own)
-            out_bytes_per_px = out.nbytes / px
-            h2d, d2h = px / t / 1e9, out.nbytes / t / 1e9
+            wire_out = n * H * ((W + 7) // 8) if (compact or bits) else out.nbytes  # bytes that cross the link downwards
+            out_bytes_per_px = wire_out / px
+            h2d, d2h = px / t / 1e9, wire_out / t / 1e9
             # one row per rank (not only the MAX): this rank's median call, its link rates, where its buffers live
-            per_rank = sharding.gather_rows(sharding.h2h_rank_row(rank, px, out.nbytes, t_own, src, out))
+            per_rank = sharding.gather_rows(sharding.h2h_rank_row(rank, px, wire_out, t_own, src, out))
             res[name] = {"value": round(px * world / t / 1e6, 1), "unit": "Mpixels/s", "ms_per_batch": round(t * 1e3, 3),
                          "ms_per_call": [round(c * 1e3, 2) for c in calls], "per_rank": per_rank,
                          "h2d_GBps_per_gpu": round(h2d, 2), "d2h_GBps_per_gpu": round(d2h, 2),
                          "link_frac": round(max(h2d, d2h) / PCIE_PEAK_GBS, 4),
+                         "host_plane_write_GBps_per_gpu": round(out.nbytes / t / 1e9, 2),
                          "bytes_over_link_per_px": round(1 + out_bytes_per_px, 4)}
             # one frame at a time (latency): pinned in, pinned out
             one_in, one_out = src[:1], out[:1]
@@ -547,8 +553,12 @@ def main():
                                 "s16 edge map out, H2D and D2H inside the timed region (as src/cuda.cu:83-101 pays them)",
                       "value": h2h["s16"]["value"], "unit": "Mpixels/s", "ms_per_batch": h2h["s16"]["ms_per_batch"],
                       "frames_per_gpu": h2h["frames_per_gpu"], "n_gpus": world,
-                      "bound": "PCIe: %.1f GB/s D2H per GPU = %.0f %% of the %.0f GB/s link spec" % (
-                          h2h["s16"]["d2h_GBps_per_gpu"], 100 * h2h["s16"]["link_frac"], PCIE_PEAK_GBS),
+                      "bound": "PCIe %s: %.1f GB/s per GPU = %.0f %% of the %.0f GB/s link spec (the other direction: %.1f GB/s)" % (
+                          ("H2D", h2h["s16"]["h2d_GBps_per_gpu"], 100 * h2h["s16"]["link_frac"], PCIE_PEAK_GBS,
+                           h2h["s16"]["d2h_GBps_per_gpu"]) if h2h["s16"]["h2d_GBps_per_gpu"] >= h2h["s16"]["d2h_GBps_per_gpu"]
+                          else ("D2H", h2h["s16"]["d2h_GBps_per_gpu"], 100 * h2h["s16"]["link_frac"], PCIE_PEAK_GBS,
+                                h2h["s16"]["h2d_GBps_per_gpu"])),
+                      "transfer": h2h["transfer"],
                       "u8_maps": h2h["u8"]["value"], "bit_maps": h2h["bits"]["value"]}
     out = {
         "metric": "Mpixels/s device-resident Canny (4K gray, frames in HBM, whole pipeline); % HBM roofline on "

@@ -48,7 +48,7 @@ EXPORTS = (
     "canny_hip_multi_gpu_release", "canny_hip_device_local_cpus", "canny_hip_selftest_cpulist_count",
     "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in", "canny_hip_host_register", "canny_hip_host_unregister",
     "canny_hip_canny_batch_bits", "canny_hip_canny_multi_gpu_bits", "canny_hip_dev_canny_bits",
-    "canny_hip_probe_copy", "canny_hip_ctx_get_option",
+    "canny_hip_probe_copy", "canny_hip_ctx_get_option", "canny_hip_selftest_expand_bits",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -134,6 +134,7 @@ def load() -> C.CDLL:
         "canny_hip_profile_get": ([p, i, C.POINTER(C.c_double), C.POINTER(C.c_long)], i),
         "canny_hip_probe_copy": ([p, p, p, C.c_size_t, i, C.POINTER(C.c_double)], i),
         "canny_hip_ctx_get_option": ([p, C.c_char_p, ip], i),
+        "canny_hip_selftest_expand_bits": ([p, i, i, i, p, i], i),
         "canny_hip_selftest_mag_angle": ([p, i, p, p], i),
         "canny_hip_selftest_div": ([p, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
         "canny_hip_selftest_div_fma": ([p, f, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
@@ -155,6 +156,20 @@ def device_count() -> int:
     n = C.c_int(0)
     load().canny_hip_device_count(C.byref(n))
     return n.value
+
+
+def expand_bits(bits: np.ndarray, height: int, width: int, u8: bool = False, threads: int = 4, out=None) -> np.ndarray:
+    """Host-only: a packed bit map (rows MSB-first, padded to bytes) -> the short (or byte) edge plane, through the same
+    thread pool the batch pipelines use for their compact transfer."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    assert bits.size == height * ((width + 7) // 8)
+    if out is None:
+        out = np.empty((height, width), np.uint8 if u8 else np.int16)
+    st = load().canny_hip_selftest_expand_bits(bits.ctypes.data_as(C.c_void_p), height, width, int(u8),
+                                               out.ctypes.data_as(C.c_void_p), threads)
+    if st:
+        raise CannyHipError(st, "selftest_expand_bits")
+    return out
 
 
 def fma_div_table():

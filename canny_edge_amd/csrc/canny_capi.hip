@@ -12,7 +12,11 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -24,6 +28,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 using namespace canny;
 
@@ -150,6 +157,129 @@ struct PinBuf { // page-locked host staging
     }
 };
 
+// ---- host-side expansion of bit maps (the "compact" transfer of the batch pipelines) -------------------------------
+// The edge map only ever holds EDGE and NOEDGE (src/utils.h:5-6), so a batch call does not have to move the
+// reference's 2 bytes per pixel over PCIe: the device packs the finished map into one bit per pixel (rows MSB-first,
+// padded to bytes: launch_edges_to_bits), that travels -- 1/16 of the s16 map --, and a small pool of host threads
+// writes the caller's short (or byte) plane from it: one 16-byte (8-byte) streaming store per bit-map byte out of a
+// 256-entry table.  The s16 batch was bound by the DOWNLOAD (51 GB/s D2H for 25.5 Gpix/s); this way it runs at the
+// rate frames can be UPLOADED, like the bit-map API, and the caller still gets the reference's plane, bit for bit.
+class ExpandPool {
+public:
+    struct Job {
+        const uint8_t *bits; // bit rows of the block (row_bytes each)
+        void *dst;           // first pixel of the block in the caller's plane
+        int rows, width, row_bytes;
+        bool to_u8;          // bytes instead of shorts
+        std::atomic<int> *left; // jobs of the chunk still to do
+    };
+    explicit ExpandPool(int n_threads)
+    {
+        for (int b = 0; b < 256; b++)
+            for (int k = 0; k < 8; k++) {
+                const bool on = (b & (0x80 >> k)) != 0; // MSB first: bit 7 is the row's first pixel of this byte
+                lut16_[b][k] = on ? 255 : 0;            // EDGE / NOEDGE
+                lut8_[b][k] = on ? 255 : 0;
+            }
+        for (int i = 0; i < n_threads; i++) threads_.emplace_back([this] { loop(); });
+    }
+    ~ExpandPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_job_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    int size() const { return (int)threads_.size(); }
+    void submit(const Job &j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            q_.push_back(j);
+        }
+        cv_job_.notify_one();
+    }
+    // blocks until `left` has reached zero; the waiting thread works on queued jobs meanwhile
+    void wait(std::atomic<int> &left)
+    {
+        while (left.load(std::memory_order_acquire) > 0) {
+            Job j;
+            bool have = false;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!q_.empty()) {
+                    j = q_.front();
+                    q_.pop_front();
+                    have = true;
+                }
+            }
+            if (have) {
+                run(j);
+            } else {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_done_.wait_for(lk, std::chrono::microseconds(50),
+                                  [&] { return left.load(std::memory_order_acquire) <= 0 || !q_.empty(); });
+            }
+        }
+    }
+
+private:
+    void loop()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_job_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return; // stop_
+                j = q_.front();
+                q_.pop_front();
+            }
+            run(j);
+        }
+    }
+    void run(const Job &j)
+    {
+        for (int r = 0; r < j.rows; r++) {
+            const uint8_t *src = j.bits + (size_t)r * j.row_bytes;
+            const int full = j.width / 8, tail = j.width % 8;
+            if (j.to_u8) {
+                uint8_t *d = (uint8_t *)j.dst + (size_t)r * j.width;
+                for (int b = 0; b < full; b++) std::memcpy(d + 8 * b, lut8_[src[b]], 8);
+                if (tail) std::memcpy(d + 8 * full, lut8_[src[full]], tail);
+            } else {
+                short *d = (short *)j.dst + (size_t)r * j.width;
+#if defined(__SSE2__)
+                if ((((uintptr_t)d) & 15) == 0) { // streaming stores: the plane is written once and not read here
+                    for (int b = 0; b < full; b++)
+                        _mm_stream_si128((__m128i *)(d + 8 * b), _mm_load_si128((const __m128i *)lut16_[src[b]]));
+                } else
+#endif
+                {
+                    for (int b = 0; b < full; b++) std::memcpy(d + 8 * b, lut16_[src[b]], 16);
+                }
+                if (tail) std::memcpy(d + 8 * full, lut16_[src[full]], 2 * tail);
+            }
+        }
+#if defined(__SSE2__)
+        _mm_sfence();
+#endif
+        if (j.left->fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lk(mu_); // pairs with wait(): no lost wake-up
+            cv_done_.notify_all();
+        }
+    }
+    alignas(16) short lut16_[256][8];
+    alignas(8) uint8_t lut8_[256][8];
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_job_, cv_done_;
+    std::deque<Job> q_;
+    bool stop_ = false;
+};
+
 struct EventPair {
     hipEvent_t a, b;
 };
@@ -199,6 +329,11 @@ struct canny_hip_ctx {
     int batch_chunk_mb = 0;
     int batch_chunk_frames = 0;
     int batch_pipe_mode = 0; // 0 = automatic, 1 = three streams per pipeline, 2 = one in-order stream per pipeline
+    // s16 / u8 batch maps travel as bit maps and are expanded by host threads (ExpandPool): 0 = automatic (on),
+    // 1 = off (the map itself is downloaded, as in rounds 1-2); expand_threads: 0 = automatic
+    int batch_compact = 0;
+    int batch_expand_threads = 0;
+    std::unique_ptr<ExpandPool> expand_pool;
     // the pipelines live as long as the context: creating a sub-context with its streams and allocating its
     // staging costs ~10 ms per call, a sixth of a 1024 x 1080p batch
     struct BatchPipe;
@@ -259,6 +394,8 @@ struct canny_hip_ctx::BatchPipe {
         bool d2h_issued = false;      // ev_d2h has been recorded during the current call
         void *retire_dst = nullptr;   // pageable output: where pin_out goes once ev_d2h has fired
         size_t retire_bytes = 0;
+        int retire_frames = 0;        // compact transfer: frames whose bit maps sit in pin_out
+        std::atomic<int> expand_left{0}; // compact transfer: expansion jobs of this slot's chunk still running
     } slot[kSlots];
 };
 
@@ -882,6 +1019,7 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)finish_pending(ctx);
+    ctx->expand_pool.reset(); // joins its threads; no job can be queued here (batch calls are synchronous)
     for (auto *w : ctx->batch_pool) destroy_batch_pipe(w);
     ctx->batch_pool.clear();
     (void)hipSetDevice(ctx->device);
@@ -932,6 +1070,8 @@ int canny_hip_ctx_get_option(const canny_hip_ctx *ctx, const char *name, int *va
     else if (!std::strcmp(name, "hysteresis_tail")) *value = ctx->hyst_tail;
     else if (!std::strcmp(name, "gaussian_path")) *value = ctx->gaussian_path;
     else if (!std::strcmp(name, "sobel_nms_path")) *value = ctx->sobel_nms_path;
+    else if (!std::strcmp(name, "tune_batch_compact")) *value = ctx->batch_compact;
+    else if (!std::strcmp(name, "batch_expand_threads")) *value = ctx->expand_pool ? ctx->expand_pool->size() : 0; // read-only
     else return CANNY_HIP_ERR_INVALID;
     return CANNY_HIP_OK;
 }
@@ -951,6 +1091,11 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) ctx->batch_chunk_mb = value;
     else if (!std::strcmp(name, "tune_batch_chunk_frames") && value <= 65535) ctx->batch_chunk_frames = value;
     else if (!std::strcmp(name, "tune_batch_pipe_mode") && value <= 2) ctx->batch_pipe_mode = value;
+    else if (!std::strcmp(name, "tune_batch_compact") && value <= 1) ctx->batch_compact = value;
+    else if (!std::strcmp(name, "tune_batch_expand_threads") && value <= 64) {
+        if (value != ctx->batch_expand_threads) ctx->expand_pool.reset();
+        ctx->batch_expand_threads = value;
+    }
     else if (!std::strcmp(name, "stream_overlap") && value <= 1) {
         int rc = bind(ctx);
         if (rc || (rc = finish_pending(ctx))) return rc;
@@ -1269,8 +1414,25 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         }
         return attr.type == hipMemoryTypeHost;
     };
-    const bool in_pinned = is_pinned(imgs), out_pinned = is_pinned(edges);
-    const bool all_pinned = in_pinned && out_pinned;
+    // Compact transfer (s16 and u8 maps): the device packs the map into bits, the bits travel, host threads expand them
+    // into the caller's plane (ExpandPool).  The caller's output buffer is then written by CPU stores: it needs no
+    // pinning and no staging copy.
+    const bool compact = fmt != kMapBits && ctx->batch_compact != 1;
+    if (compact && !ctx->expand_pool) {
+        // 12 threads write ~110 GB/s of shorts on the test host, twice what one GPU's upload can feed; never more
+        // than the CPUs this thread may run on (the sharder and bench.py bind themselves to the GPU's local CPUs
+        // first, and the pool's threads inherit that mask)
+        int n = ctx->batch_expand_threads;
+        if (n <= 0) {
+            cpu_set_t set;
+            const int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 1;
+            n = std::max(1, std::min(12, avail - 1));
+        }
+        ctx->expand_pool.reset(new (std::nothrow) ExpandPool(n));
+        if (!ctx->expand_pool) return CANNY_HIP_ERR_RUNTIME;
+    }
+    const bool in_pinned = is_pinned(imgs), out_pinned = compact ? false : is_pinned(edges);
+    const bool all_pinned = in_pinned && (out_pinned || compact);
     // Defaults from the sweep on an MI355X box (tools/probe_batch_sweep.py, 128 x 4K and 256 x 1080p):
     //   pinned buffers:   ONE three-stream pipeline, 24 MB chunks -- s16 maps 25.3 Gpix/s (D2H 50.6 GB/s: the link's
     //                     rate with both directions busy), u8 maps 45.4 Gpix/s; a second pipeline only adds streams
@@ -1297,6 +1459,9 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         for (int i = 0; i < n_workers; i++)
             if ((rc = ensure_copy_streams(ctx, *ctx->batch_pool[i]))) return rc;
     const size_t out_frame = map_frame_bytes(fmt, height, width); // bytes of one frame's map as the caller gets it
+    const size_t bits_frame = map_frame_bytes(kMapBits, height, width);
+    const size_t wire_frame = compact ? bits_frame : out_frame;   // ... and as it crosses the link
+    const int row_bytes = (width + 7) / 8;
 
     auto worker = [&](int wid) {
         Pipe &P = *ctx->batch_pool[wid];
@@ -1310,19 +1475,20 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             return;
         }
         const int my_chunks = (n_chunks - wid + n_workers - 1) / n_workers;
-        const size_t in_bytes = frame_px * chunk, out_bytes = out_frame * chunk;
+        const size_t in_bytes = frame_px * chunk, out_bytes = wire_frame * chunk;
         hipError_t e = hipSuccess;
         constexpr int n_slots = Pipe::kSlots;
         for (int k = 0; k < std::min(my_chunks, n_slots) && e == hipSuccess; k++) {
             Pipe::Slot &S = P.slot[k];
             S.d2h_issued = false;
             S.retire_dst = nullptr;
+            S.expand_left.store(0);
             // pageable caller buffers are staged through pinned memory; pinned ones are DMA'd in place
             if (!in_pinned) e = S.pin_in.ensure(in_bytes, device);
             if (e == hipSuccess && !out_pinned) e = S.pin_out.ensure(out_bytes, device);
             if (e == hipSuccess) e = S.d_in.ensure(in_bytes);
             if (e == hipSuccess) e = S.d_out.ensure(frame_px * chunk * sizeof(short));
-            if (e == hipSuccess && fmt != kMapS16) e = S.d_out8.ensure(out_bytes);
+            if (e == hipSuccess && (fmt != kMapS16 || compact)) e = S.d_out8.ensure(out_bytes);
         }
         if (e != hipSuccess) {
             st = fail(sub, e, "batch staging allocation");
@@ -1361,7 +1527,29 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             Pipe::Slot &S = P.slot[j % n_slots];
             if (!S.retire_dst) return hipSuccess;
             hipError_t err = hipEventSynchronize(S.ev_d2h);
-            if (err == hipSuccess) std::memcpy(S.retire_dst, S.pin_out.p, S.retire_bytes);
+            if (err == hipSuccess && compact) {
+                // the chunk's bit maps have landed in pin_out: hand them to the expansion pool in blocks of rows and
+                // go on (the pool's threads write the caller's plane while the next chunks move)
+                constexpr int kBlockRows = 128;
+                const int blocks_per_frame = (height + kBlockRows - 1) / kBlockRows;
+                S.expand_left.store(S.retire_frames * blocks_per_frame, std::memory_order_release);
+                const size_t px_bytes = fmt == kMapU8 ? 1 : sizeof(short);
+                for (int f = 0; f < S.retire_frames; f++)
+                    for (int b = 0; b < blocks_per_frame; b++) {
+                        const int r0 = b * kBlockRows;
+                        ExpandPool::Job job;
+                        job.bits = (const uint8_t *)S.pin_out.p + (size_t)f * bits_frame + (size_t)r0 * row_bytes;
+                        job.dst = (unsigned char *)S.retire_dst + ((size_t)f * frame_px + (size_t)r0 * width) * px_bytes;
+                        job.rows = std::min(kBlockRows, height - r0);
+                        job.width = width;
+                        job.row_bytes = row_bytes;
+                        job.to_u8 = fmt == kMapU8;
+                        job.left = &S.expand_left;
+                        ctx->expand_pool->submit(job);
+                    }
+            } else if (err == hipSuccess) {
+                std::memcpy(S.retire_dst, S.pin_out.p, S.retire_bytes);
+            }
             S.retire_dst = nullptr;
             return err;
         };
@@ -1380,11 +1568,11 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
                            (short *)S.d_out.p);
             if (st) break;
             const void *d_res = S.d_out.p;
-            if (fmt != kMapS16) { // narrow on the device: the D2H copy is what these variants are for
-                e = fmt == kMapU8 ? launch_edges_to_u8((const int16_t *)S.d_out.p, (uint8_t *)S.d_out8.p, frame_px * nf,
-                                                       sub->stream)
-                                  : launch_edges_to_bits((const int16_t *)S.d_out.p, (uint8_t *)S.d_out8.p, height, width,
-                                                         nf, sub->stream);
+            if (fmt != kMapS16 || compact) { // narrow on the device: the D2H copy is what these variants are for
+                e = (fmt == kMapU8 && !compact)
+                        ? launch_edges_to_u8((const int16_t *)S.d_out.p, (uint8_t *)S.d_out8.p, frame_px * nf, sub->stream)
+                        : launch_edges_to_bits((const int16_t *)S.d_out.p, (uint8_t *)S.d_out8.p, height, width, nf,
+                                               sub->stream);
                 if (e != hipSuccess) break;
                 d_res = S.d_out8.p;
             }
@@ -1400,7 +1588,9 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             // download of chunk j (pin_out of this slot was retired kSlots - 1 iterations ago)
             where = "batch D2H";
             unsigned char *dst = (unsigned char *)edges + (size_t)f0 * out_frame;
-            const size_t bytes = out_frame * nf;
+            const size_t bytes = wire_frame * nf;
+            // compact transfer: the expansion of the chunk that used this slot's pin_out before must have read it
+            if (compact) ctx->expand_pool->wait(S.expand_left);
             if ((e = hipStreamWaitEvent(s_d2h, S.ev_comp, 0)) != hipSuccess) break;
             if ((e = hipMemcpyAsync(out_pinned ? (void *)dst : S.pin_out.p, d_res, bytes, hipMemcpyDeviceToHost,
                                     s_d2h)) != hipSuccess)
@@ -1410,10 +1600,13 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
             if (!out_pinned) {
                 S.retire_dst = dst;
                 S.retire_bytes = bytes;
+                S.retire_frames = nf;
             }
             if (j > 0 && (e = retire(j - 1)) != hipSuccess) break;
         }
         if (e == hipSuccess && st == CANNY_HIP_OK && my_chunks > 0) e = retire(my_chunks - 1);
+        if (compact) // every plane block of this pipeline has been written when the call returns (also after errors)
+            for (auto &sl : P.slot) ctx->expand_pool->wait(sl.expand_left);
         // nothing of this call may still be in flight when it returns (also after an error: the slots are reused)
         hipError_t e2 = hipStreamSynchronize(s_h2d);
         hipError_t e3 = hipStreamSynchronize(sub->stream);
@@ -1460,7 +1653,7 @@ struct MultiGpuState {
     std::mutex mu;
     std::vector<canny_hip_ctx *> shard_ctx; // index = shard
     std::vector<int> shard_dev;
-    int batch_workers = 0, batch_chunk_mb = 0, batch_chunk_frames = 0, batch_pipe_mode = 0;
+    int batch_workers = 0, batch_chunk_mb = 0, batch_chunk_frames = 0, batch_pipe_mode = 0, batch_compact = 0;
     int allow_device_reuse = 0; // shards beyond the device count wrap around (testing the sharder on a small box)
     int numa_affinity = 1;
 };
@@ -1501,6 +1694,7 @@ static int multi_gpu_impl(const unsigned char *imgs, int n_frames, float sigma, 
         ctx->batch_chunk_mb = g_mgpu.batch_chunk_mb;
         ctx->batch_chunk_frames = g_mgpu.batch_chunk_frames;
         ctx->batch_pipe_mode = g_mgpu.batch_pipe_mode;
+        ctx->batch_compact = g_mgpu.batch_compact;
         // run next to the GPU: this thread and the pipeline threads it starts inherit the mask.  The caller's own
         // thread (shard 0) gets its mask back afterwards.
         cpu_set_t local, saved;
@@ -1548,6 +1742,7 @@ int canny_hip_multi_gpu_set_option(const char *name, int value)
     else if (!std::strcmp(name, "tune_batch_chunk_mb") && value <= 1024) g_mgpu.batch_chunk_mb = value;
     else if (!std::strcmp(name, "tune_batch_chunk_frames") && value <= 65535) g_mgpu.batch_chunk_frames = value;
     else if (!std::strcmp(name, "tune_batch_pipe_mode") && value <= 2) g_mgpu.batch_pipe_mode = value;
+    else if (!std::strcmp(name, "tune_batch_compact") && value <= 1) g_mgpu.batch_compact = value;
     else if (!std::strcmp(name, "allow_device_reuse") && value <= 1) g_mgpu.allow_device_reuse = value;
     else if (!std::strcmp(name, "numa_affinity") && value <= 1) g_mgpu.numa_affinity = value;
     else return CANNY_HIP_ERR_INVALID;
@@ -1832,6 +2027,30 @@ int canny_hip_probe_copy(canny_hip_ctx *ctx, const void *d_src, void *d_dst, siz
     (void)hipEventDestroy(b);
     HIP_TRY(ctx, e);
     *avg_ms = total / launches;
+    return CANNY_HIP_OK;
+}
+
+// Host-only: the batch pipelines' bit-map expansion (ExpandPool) on a caller-supplied bit map; needs no device.
+int canny_hip_selftest_expand_bits(const unsigned char *bits, int height, int width, int to_u8, void *out, int n_threads)
+{
+    if (!bits || !out || height < 1 || width < 1 || n_threads < 1 || n_threads > 64) return CANNY_HIP_ERR_INVALID;
+    ExpandPool pool(n_threads);
+    constexpr int kBlockRows = 128;
+    const int row_bytes = (width + 7) / 8, blocks = (height + kBlockRows - 1) / kBlockRows;
+    std::atomic<int> left{blocks};
+    for (int b = 0; b < blocks; b++) {
+        ExpandPool::Job job;
+        const int r0 = b * kBlockRows;
+        job.bits = bits + (size_t)r0 * row_bytes;
+        job.dst = (unsigned char *)out + (size_t)r0 * width * (to_u8 ? 1 : sizeof(short));
+        job.rows = std::min(kBlockRows, height - r0);
+        job.width = width;
+        job.row_bytes = row_bytes;
+        job.to_u8 = to_u8 != 0;
+        job.left = &left;
+        pool.submit(job);
+    }
+    pool.wait(left);
     return CANNY_HIP_OK;
 }
 

@@ -125,6 +125,9 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *                    high-priority stream beside the next call's Gaussian instead of in order before it
  *                    (no gain on 128 x 4K batches, kept for A/B)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
+ *   "tune_batch_compact": 0 (default) the s16 / u8 maps of the batch calls cross PCIe as 1-bit maps and are expanded
+ *       into the caller's plane by host threads ("tune_batch_expand_threads": 0 = automatic, up to 12); 1 = the map
+ *       itself is downloaded (rounds 1-2).  Same planes bit for bit
  *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide; the packed-i16 kernel only)
  *   "tune_sobel_variant": 0 (default) automatic -- the f32 marching arithmetic (4 waves per SIMD) for the fused
  *       Sobel+NMS+classify kernel of canny(), round 2's packed-i16 arithmetic (3 waves per SIMD) for the s16 -> s16
@@ -140,7 +143,8 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *                    region that needs one kernel's duration enables that stage only.
  *   "profile_sample_interval": N >= 1 (default 1): only every N-th launch group of a stage gets its event pair */
 int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value);
-/* Reads back "smoothed_u8", "fuse_classify", "hysteresis_tail", "gaussian_path", "sobel_nms_path", and the read-only
+/* Reads back "smoothed_u8", "fuse_classify", "hysteresis_tail", "gaussian_path", "sobel_nms_path", "tune_batch_compact",
+ * the read-only "batch_expand_threads" (threads of the expansion pool once a batch call has created it) and the read-only
  * "last_canny_smoothed_u8": 1 if the context's last canny call really ran on the u8 smoothed plane (the option is a
  * request: windows beyond 17, asymmetric taps and shapes the fused kernel does not take fall back to the s16 plane).
  * bench.py uses it to price the kernel it timed with the bytes that kernel moved. */
@@ -317,6 +321,10 @@ int canny_hip_selftest_div_fma(canny_hip_ctx *ctx, float divisor, float c, unsig
                                float *largest_mismatching_dividend);
 /* Entry `index` of the built-in (divisor, c) table the kernels use; CANNY_HIP_ERR_INVALID past the end. */
 int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c);
+/* Host-only (needs no device): the expansion step of the batch pipelines' compact transfer -- a bit map (rows MSB-first,
+ * padded to bytes: height * ((width + 7) / 8) bytes) becomes the reference's short plane (0 / 255), or with to_u8 != 0 a
+ * byte plane, written by n_threads pool threads exactly as canny_hip_canny_batch does it. */
+int canny_hip_selftest_expand_bits(const unsigned char *bits, int height, int width, int to_u8, void *out, int n_threads);
 /* Host-only: number of CPUs in a sysfs-style list ("0-3,8,10-11" -> 7; 0 if malformed) -- the parser behind the
  * sharder's NUMA binding. */
 int canny_hip_selftest_cpulist_count(const char *text);

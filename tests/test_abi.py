@@ -148,3 +148,24 @@ def test_public_headers_are_plain_c(tmp_path):
     assert out.returncode == 0, out.stderr
     version, _status, counted, frames_status = out.stdout.split()
     assert int(version) >= 200 and counted == "1" and frames_status == "2"   # "xx" is not a JPEG: CANNY_FRAMES_ERR_FORMAT
+
+
+@pytest.mark.parametrize("u8", [False, True], ids=["short_plane", "byte_plane"])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (5, 8), (7, 9), (130, 64), (257, 203), (300, 3840), (2160, 131)])
+def test_bit_map_expansion_of_the_compact_transfer(shape, u8):
+    """Host logic of the batch pipelines (no GPU involved): the 1-bit edge map that crosses PCIe is expanded into the
+    reference's short plane (EDGE = 255 / NOEDGE = 0, src/utils.h:5-6), or a byte plane, by the library's thread pool.
+    Checked against numpy for widths that are and are not multiples of 8, one and several row blocks, unaligned output."""
+    h, w = shape
+    rng = np.random.default_rng(h * 4099 + w)
+    plane = (rng.random((h, w)) < 0.3)
+    bits = np.packbits(plane, axis=-1)                       # rows MSB-first, padded to bytes
+    want = (plane * 255).astype(np.uint8 if u8 else np.int16)
+    for threads in (1, 5):
+        got = capi.expand_bits(bits, h, w, u8=u8, threads=threads)
+        assert np.array_equal(got, want), (shape, u8, threads)
+    # an output that starts at an odd element (no 16-byte alignment: the streaming-store path must not be taken)
+    backing = np.full(h * w + 8, 77, want.dtype)
+    out = backing[3:3 + h * w].reshape(h, w)
+    capi.expand_bits(bits, h, w, u8=u8, threads=3, out=out)
+    assert np.array_equal(out, want) and (backing[:3] == 77).all() and (backing[3 + h * w:] == 77).all()

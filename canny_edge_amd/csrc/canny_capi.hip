@@ -1343,6 +1343,10 @@ int canny_hip_find_edge_pixels(canny_hip_ctx *ctx, short *edge_candidates, unsig
     return d2h_sync(ctx, visited, ctx->io[1].p, n);
 }
 
+enum MapFormat { kMapS16 = 0, kMapU8 = 1, kMapBits = 2 };
+static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
+                            int max_val, int height, int width, void *edges, MapFormat fmt);
+
 int canny_hip_canny(canny_hip_ctx *ctx, const unsigned char *img, float sigma, int min_val, int max_val, int height,
                     int width, short *edges)
 {
@@ -1351,6 +1355,11 @@ int canny_hip_canny(canny_hip_ctx *ctx, const unsigned char *img, float sigma, i
     if (!img || !edges) return CANNY_HIP_ERR_INVALID;
     if ((rc = check_dims(height, width, 1))) return rc;
     size_t n = npx(height, width, 1);
+    // Frames of a megapixel and more go through the batch pipeline as a batch of one: pinned staging for the upload and
+    // the compact transfer for the map (1/16 of the bytes down, host threads write the caller's plane) -- the caller's
+    // buffers here are ordinary new[] / cv::Mat memory, for which a plain 2-byte-per-pixel download is slowest of all.
+    if (n >= (1u << 20) && height >= 2 && width >= 2 && ctx->batch_compact != 1)
+        return canny_batch_impl(ctx, img, 1, sigma, min_val, max_val, height, width, edges, kMapS16);
     if ((rc = h2d(ctx, ctx->io[0], img, n))) return rc;
     HIP_TRY(ctx, ctx->io[1].ensure(n * 2));
     if ((rc = dev_canny(ctx, (const unsigned char *)ctx->io[0].p, sigma, min_val, max_val, height, width, 1,
@@ -1384,7 +1393,6 @@ int canny_hip_shard_range(int n_frames, int rank, int world, int *begin, int *en
 //   several pipelines run side by side to get enough copy bandwidth.
 // What a batch call returns per frame: the reference's short plane (0 / 255), the same as bytes, or one bit per pixel
 // (rows MSB-first, padded to whole bytes -- launch_edges_to_bits).
-enum MapFormat { kMapS16 = 0, kMapU8 = 1, kMapBits = 2 };
 static size_t map_frame_bytes(MapFormat fmt, int height, int width)
 {
     if (fmt == kMapBits) return (size_t)height * (size_t)((width + 7) / 8);
@@ -1419,14 +1427,16 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
     // pinning and no staging copy.
     const bool compact = fmt != kMapBits && ctx->batch_compact != 1;
     if (compact && !ctx->expand_pool) {
-        // 12 threads write ~110 GB/s of shorts on the test host, twice what one GPU's upload can feed; never more
-        // than the CPUs this thread may run on (the sharder and bench.py bind themselves to the GPU's local CPUs
-        // first, and the pool's threads inherit that mask)
+        // 8 threads (profiles/r03/compact_transfer_threads_chunks.txt, 128 x 4K: 2 / 4 / 8 / 16 / 24 threads 52.7 / 53.0 /
+        // 53.1 / 52.7 / 52.4 Gpix/s, 12 threads 49.8 both times it was measured, the plain download 25.4): even two
+        // keep up with one GPU's upload -- streaming stores, and the pipeline thread works on blocks while it waits --,
+        // so this is headroom for slower hosts.  Never more than the CPUs this thread may run on (the sharder and
+        // bench.py bind themselves to the GPU's local CPUs first, and the pool's threads inherit that mask)
         int n = ctx->batch_expand_threads;
         if (n <= 0) {
             cpu_set_t set;
             const int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : 1;
-            n = std::max(1, std::min(12, avail - 1));
+            n = std::max(1, std::min(8, avail - 1));
         }
         ctx->expand_pool.reset(new (std::nothrow) ExpandPool(n));
         if (!ctx->expand_pool) return CANNY_HIP_ERR_RUNTIME;

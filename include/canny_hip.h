@@ -126,7 +126,7 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *                    (no gain on 128 x 4K batches, kept for A/B)
  *   "tune_sobel_seg": rows per wave segment of the marching Sobel+NMS kernel, 0 = automatic
  *   "tune_batch_compact": 0 (default) the s16 / u8 maps of the batch calls cross PCIe as 1-bit maps and are expanded
- *       into the caller's plane by host threads ("tune_batch_expand_threads": 0 = automatic, up to 12); 1 = the map
+ *       into the caller's plane by host threads ("tune_batch_expand_threads": 0 = automatic, up to 8); 1 = the map
  *       itself is downloaded (rounds 1-2).  Same planes bit for bit
  *   "tune_sobel_px": 0 (default) 8 pixels per lane, 1 four pixels per lane (process-wide; the packed-i16 kernel only)
  *   "tune_sobel_variant": 0 (default) automatic -- the f32 marching arithmetic (4 waves per SIMD) for the fused

@@ -167,12 +167,33 @@ struct PinBuf { // page-locked host staging
 class ExpandPool {
 public:
     struct Job {
-        const uint8_t *bits; // bit rows of the block (row_bytes each)
-        void *dst;           // first pixel of the block in the caller's plane
+        const uint8_t *bits; // bit rows of the block (row_bytes each) -- or, for a copy job, the source bytes
+        void *dst;           // first pixel of the block in the caller's plane -- or the copy's destination
         int rows, width, row_bytes;
         bool to_u8;          // bytes instead of shorts
         std::atomic<int> *left; // jobs of the chunk still to do
+        size_t copy_bytes = 0;  // != 0: a plain memcpy of that many bytes (staging of pageable input frames)
     };
+    // dst[0, bytes) = src[0, bytes), split over the pool in 1 MB pieces; returns when it is done (the caller works too)
+    void parallel_copy(void *dst, const void *src, size_t bytes)
+    {
+        constexpr size_t kPiece = 1u << 20;
+        const int n = (int)((bytes + kPiece - 1) / kPiece);
+        if (n <= 1) {
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        std::atomic<int> left{n};
+        for (int i = 0; i < n; i++) {
+            Job j{};
+            j.bits = (const uint8_t *)src + (size_t)i * kPiece;
+            j.dst = (uint8_t *)dst + (size_t)i * kPiece;
+            j.copy_bytes = std::min(kPiece, bytes - (size_t)i * kPiece);
+            j.left = &left;
+            submit(j);
+        }
+        wait(left);
+    }
     explicit ExpandPool(int n_threads)
     {
         for (int b = 0; b < 256; b++)
@@ -242,7 +263,8 @@ private:
     }
     void run(const Job &j)
     {
-        for (int r = 0; r < j.rows; r++) {
+        if (j.copy_bytes) std::memcpy(j.dst, j.bits, j.copy_bytes);
+        for (int r = 0; r < (j.copy_bytes ? 0 : j.rows); r++) {
             const uint8_t *src = j.bits + (size_t)r * j.row_bytes;
             const int full = j.width / 8, tail = j.width % 8;
             if (j.to_u8) {
@@ -1426,7 +1448,7 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
     // into the caller's plane (ExpandPool).  The caller's output buffer is then written by CPU stores: it needs no
     // pinning and no staging copy.
     const bool compact = fmt != kMapBits && ctx->batch_compact != 1;
-    if (compact && !ctx->expand_pool) {
+    if (ctx->batch_compact != 1 && !ctx->expand_pool) { // (also stages pageable input frames, see below)
         // 8 threads (profiles/r03/compact_transfer_threads_chunks.txt, 128 x 4K: 2 / 4 / 8 / 16 / 24 threads 52.7 / 53.0 /
         // 53.1 / 52.7 / 52.4 Gpix/s, 12 threads 49.8 both times it was measured, the plain download 25.4): even two
         // keep up with one GPU's upload -- streaming stores, and the pipeline thread works on blocks while it waits --,
@@ -1442,7 +1464,12 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
         if (!ctx->expand_pool) return CANNY_HIP_ERR_RUNTIME;
     }
     const bool in_pinned = is_pinned(imgs), out_pinned = compact ? false : is_pinned(edges);
-    const bool all_pinned = in_pinned && (out_pinned || compact);
+    // Pageable INPUT frames are staged into the chunk slot's pinned buffer by the same pool (1 MB pieces, the
+    // pipeline thread works too): ~90 GB/s of memcpy against the link's 54, so ordinary caller memory runs through
+    // the same single three-stream pipeline as pinned memory.  (Rounds 1-2: six single-stream pipelines whose
+    // threads each copied their own chunks -- 20-35 Gpix/s and bimodal from call to call.)
+    const bool pool_staging = !in_pinned && ctx->expand_pool != nullptr;
+    const bool all_pinned = (in_pinned || pool_staging) && (out_pinned || compact);
     // Defaults from the sweep on an MI355X box (tools/probe_batch_sweep.py, 128 x 4K and 256 x 1080p):
     //   pinned buffers:   ONE three-stream pipeline, 24 MB chunks -- s16 maps 25.3 Gpix/s (D2H 50.6 GB/s: the link's
     //                     rate with both directions busy), u8 maps 45.4 Gpix/s; a second pipeline only adds streams
@@ -1525,7 +1552,10 @@ static int canny_batch_impl(canny_hip_ctx *ctx, const unsigned char *imgs, int n
                 if (err != hipSuccess) return err;
             }
             if (!in_pinned) {
-                std::memcpy(S.pin_in.p, src, frame_px * nf);
+                if (pool_staging)
+                    ctx->expand_pool->parallel_copy(S.pin_in.p, src, frame_px * nf);
+                else
+                    std::memcpy(S.pin_in.p, src, frame_px * nf);
                 src = (const unsigned char *)S.pin_in.p;
             }
             err = hipMemcpyAsync(S.d_in.p, src, frame_px * nf, hipMemcpyHostToDevice, s_h2d);

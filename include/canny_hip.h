@@ -116,9 +116,10 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *   "tune_batch_workers", "tune_batch_chunk_mb", "tune_batch_chunk_frames", "tune_batch_pipe_mode":
  *                    canny_hip_canny_batch's pipelines (host threads), the chunk size in megabytes of input or in
  *                    frames (frames win) and the stream structure of a pipeline (1 = upload, compute and download
- *                    stream chained by events, 2 = one in-order stream); 0 (default) = automatic: one three-stream
- *                    pipeline x 24 MB chunks between pinned buffers, six single-stream pipelines x 8 MB when a
- *                    pageable buffer has to be staged.  HIP multiplexes a process's streams onto 4 hardware queues by
+ *                    stream chained by events, 2 = one in-order stream); 0 (default) = automatic: ONE three-stream
+ *                    pipeline x 24 MB chunks, for pinned and for ordinary caller memory alike (round 3: pageable input
+ *                    is staged by the library's thread pool, the output is written by it: "tune_batch_compact"; with
+ *                    tune_batch_compact = 1 pageable buffers fall back to six single-stream pipelines x 8 MB).  HIP multiplexes a process's streams onto 4 hardware queues by
  *                    default (GPU_MAX_HW_QUEUES): a host application with many streams of its own should raise that
  *                    limit, or the three streams of the pipeline end up sharing a queue and serialise
  *   "stream_overlap": 0 (default) / 1 -- canny_hip_dev_canny_stream: the sweeps left in flight run on a second,
@@ -193,8 +194,11 @@ int canny_hip_canny(canny_hip_ctx *ctx, const unsigned char *img, float sigma, i
 /* n_frames contiguous frames in, n_frames edge maps out, frame i of the output = canny() of frame i (the
  * reference calls canny() once per captured frame, src/main.cpp:120-137).  The batch is cut into chunks; the
  * upload of chunk j+1, the kernels of chunk j and the download of chunk j-1 run concurrently on three streams
- * chained by events (BASELINE config 3).  Buffers from canny_hip_host_alloc (or any pinned / registered host
- * memory) are DMA'd in place; pageable buffers are staged through pinned memory by the pipeline threads. */
+ * chained by events (BASELINE config 3).  Input frames in pinned / registered host memory (canny_hip_host_alloc, ...)
+ * are DMA'd in place, ordinary (pageable) input is staged through pinned chunk buffers by the library's thread pool.
+ * The finished maps cross PCIe as 1-bit maps and the same pool writes the caller's plane from them ("tune_batch_compact",
+ * default), so the OUTPUT buffer needs no pinning: 48-53 Gpixel/s on 4K frames, bound by the upload (src/cuda.cu:83-101
+ * moves every plane both ways in full). */
 int canny_hip_canny_batch(canny_hip_ctx *ctx, const unsigned char *imgs, int n_frames, float sigma, int min_val,
                           int max_val, int height, int width, short *edges);
 /* Same, but the edge maps come back as 8-bit planes (NOEDGE = 0, EDGE = 255: the values of src/utils.h:5-6
@@ -216,7 +220,7 @@ int canny_hip_canny_batch_bits(canny_hip_ctx *ctx, const unsigned char *imgs, in
  * (pipelines, streams, staging) are created on first use and kept until canny_hip_multi_gpu_release(); each
  * shard's threads are bound to the CPUs local to its GPU (sysfs local_cpulist) for the duration of the call.
  * One sharded call runs at a time per process.  Pinned caller buffers are DMA'd in place (allocate them on
- * the right NUMA node for best results); pageable ones are staged by six single-stream pipelines per GPU. */
+ * the right NUMA node for best results); pageable ones are staged by each shard's thread pool. */
 int canny_hip_canny_multi_gpu(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,
                               int height, int width, short *edges, int n_devices);
 int canny_hip_canny_multi_gpu_u8(const unsigned char *imgs, int n_frames, float sigma, int min_val, int max_val,

@@ -550,13 +550,16 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
 
     // lane-varying border constants (COL_EDGE only).  Out-of-image columns load as zero, so a = b = 0 there:
     // "columns dropped" (gy) needs nothing, "column clamp" (gx) is gx -= a[0] at column 0 and gx += a[e] at column W-1.
-    // Two registers carry all of it: elast = index of column W-1 relative to this lane's pixel 0 (>= 7: every pixel
-    // inside; -1: every pixel outside, also for the halo lane left of column 0), from which "pixel e is inside" is the
-    // sign of e - 1 - elast, and fix_l.
+    // elast = index of column W-1 relative to this lane's pixel 0 (>= 7: every pixel inside; -1: every pixel outside,
+    // also for the halo lane left of column 0): "pixel e is inside" is the sign of e - 1 - elast.
     const float fix_l = (COL_EDGE && x0 == 0) ? 1.0f : 0.0f; // column 0 is always pixel 0 of a lane (x0 % 8 == 0)
-    int elast = (x0 < 0) ? -1 : W - 1 - x0;
-    if (COL_EDGE) asm volatile("" : "+v"(elast)); // keep the eight masks out of registers: recomputed per row
-    auto inside = [&](int e) { return (e - 1 - elast) >> 31; }; // all ones iff x0 + e lies inside the image
+    const int elast = (x0 < 0) ? -1 : W - 1 - x0;
+    // The nine masks live in registers for the whole segment (border strips have the room: 115 of 128 VGPRs);
+    // recomputing them per row cost two instructions per pixel in a quarter of a 4K frame's waves.
+    int in_m[PX + 1];
+#pragma unroll
+    for (int e = 0; e <= PX; e++) in_m[e] = COL_EDGE ? (e - 1 - elast) >> 31 : -1;
+    auto inside = [&](int e) { return in_m[e]; }; // all ones iff x0 + e lies inside the image
 
     auto load_row = [&](int r, uint32_t (&p)[NP]) {
 #pragma unroll

@@ -1131,7 +1131,7 @@ int canny_hip_ctx_set_option(canny_hip_ctx *ctx, const char *name, int value)
     else if (!std::strcmp(name, "tune_plane_stores") && value <= 1) sobel_nms_set_plane_store_variant(value); // process-wide
     else if (!std::strcmp(name, "gaussian_fma_div") && value <= 1) gaussian_set_fma_div(value != 0); // process-wide
     else if (!std::strcmp(name, "tune_finalize_mode") && value <= 1) hyst_set_finalize_mode(value);   // process-wide
-    else if (!std::strcmp(name, "tune_gaussian_variant") && value <= 2) gaussian_set_march_variant(value); // process-wide
+    else if (!std::strcmp(name, "tune_gaussian_variant") && value <= 4) gaussian_set_march_variant(value); // process-wide
     else if (!std::strcmp(name, "tune_gaussian_seg") && value <= 8192) gaussian_set_seg_target(value);      // process-wide
     else return CANNY_HIP_ERR_INVALID;
     return CANNY_HIP_OK;

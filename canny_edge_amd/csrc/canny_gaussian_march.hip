@@ -294,16 +294,32 @@ __device__ __forceinline__ void for_each_phase(F &&f, std::integer_sequence<int,
 // dword store per lane and row instead of an 8-byte one.  (v_cvt_pk_u8_f32 would convert and pack in one
 // instruction, but it rounds to nearest -- measured on the device: 41.9 M of the 1.13 G floats in [0,256] differ
 // from the truncating cast -- so the conversion stays v_cvt_i32_f32.)
-template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV, bool USE_LUT, bool OUT_U8 = false>
-__device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussTaps &t, const float *lut,
+//
+// SYS ("systolic" row pass, the default): the running SUM travels instead of the products.  A lane loads the four
+// pixels x0+C .. x0+C+3 -- the LAST terms of its own four outputs x0 .. x0+3 --, starts the sums of the four outputs
+// whose FIRST term is one of its pixels, and hands every unfinished sum to its right neighbour, which adds its own
+// pixels' products one by one (the first of them in the same instruction that takes the sum over: a DPP add) and
+// hands it on.  A sum visits floor((j+2C)/4)+1 lanes, so a row costs exactly 4*2C adds per lane of which
+// sum_j floor((j+2C)/4) cross a lane (window 11: 40 adds, 10 of them DPP) where the product-fetching form above needs
+// 44 with 19 DPP; every add has the reference's operands in the reference's order, whichever lane executes it.  The
+// halo is on the left only (SysCfg::NL lanes), and the loads sit C bytes right of the (dword aligned) stores.
+template <int C>
+struct SysCfg {
+    static constexpr int NL = (3 + 2 * C) / 4;       // lanes a sum crosses at most = halo lanes (all on the left)
+    static constexpr int SW = (64 - NL) * 4;         // output columns per strip
+};
+
+template <int C, bool COL_EDGE, bool ROW_EDGE, bool FMA_DIV, bool USE_LUT, bool OUT_U8 = false, bool SYS = false>
+__device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussTaps &t, const float *lut, float *wts,
                                                 float fma_c = 0.0f)
 {
     static_assert(!FMA_DIV || (!COL_EDGE && !ROW_EDGE), "FMA_DIV needs a single wave-uniform divisor");
     constexpr int HL = MarchCfg<C>::HL, RING = 2 * C + 1;
     static_assert(HL <= 2, "products travel at most two lanes");
     const int H = jb.H, W = jb.W, x0 = jb.x0, ybeg = jb.ybeg, yend = jb.yend, lane = jb.lane;
-    const bool owner = lane >= HL && lane < 64 - HL && x0 < W;
-    const bool full4 = x0 >= 0 && x0 + 3 < W;
+    const int xin = x0 + (SYS ? C : 0);                  // first of the four columns this lane LOADS
+    const bool owner = (SYS ? lane >= SysCfg<C>::NL : (lane >= HL && lane < 64 - HL)) && x0 < W;
+    const bool full4 = x0 >= 0 && x0 + 3 < W;            // the four columns stored
 
     float T[C + 1]; // taps by distance from the centre
 #pragma unroll
@@ -321,12 +337,9 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 #pragma unroll
     for (int k = 1; k < RING; k++) cnt_full = __fadd_rn(cnt_full, t.tap[k]);
     const float inv_full = __fdiv_rn(1.0f, cnt_full);
-    float cnt_h[4], inv_h[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        cnt_h[j] = cnt_full;
-        inv_h[j] = inv_full;
-    }
+    // At the column borders every lane has four weights of its own.  They (and their reciprocals) live in the lane's
+    // LDS slot `wts`, not in eight registers: the border strips are the register-hungriest instantiation and the one
+    // that spilled (private segment -> every wave of the launch pays for scratch).
     if (COL_EDGE) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -337,33 +350,66 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
                 int xx = x + k - C;
                 if (xx >= 0 && xx < W) c = __fadd_rn(c, t.tap[k]);
             }
-            cnt_h[j] = (x >= 0 && x < W) ? c : 1.0f;
-            inv_h[j] = __fdiv_rn(1.0f, cnt_h[j]);
+            const float cnt = (x >= 0 && x < W) ? c : 1.0f;
+            wts[j] = cnt;
+            wts[4 + j] = __fdiv_rn(1.0f, cnt);
         }
     }
+    uint32_t wts_off = 0; // opaque zero added to the slot's address at every use, so that the reads stay in the loop
+    auto row_quot = [&](float (&v)[4]) { // v[i] / (weight of output column i), in place
+        if (FMA_DIV) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = __fmaf_rn(v[i], fma_c, v[i]);
+        } else if (COL_EDGE) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            asm volatile("" : "+v"(wts_off));
+            const float *w = reinterpret_cast<const float *>(reinterpret_cast<const char *>(wts) + wts_off);
+            const f32x4 cw = *reinterpret_cast<const f32x4 *>(w), iw = *reinterpret_cast<const f32x4 *>(w + 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = div_by(v[i], cw[i], iw[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = div_by(v[i], cnt_full, inv_full);
+        }
+    };
 
     // Lane offsets of the row loads and stores, passed through an empty asm at every use: the optimiser then cannot
     // fold them into loop-invariant 64-bit VGPR pointers, and the addresses stay "uniform row base (SGPR pair) +
     // 32-bit lane offset" (saddr form).  Because the variable itself is what the asm "changes", its old value is
     // dead at that point and no register copy is needed (opaque_offset() on a loop-invariant value costs a v_mov
     // per use).  Both are only used where x0 >= 0.
+    // (The systolic form loads C bytes right of x0: the constant goes into the uniform base.)
     uint32_t ld_off = (uint32_t)x0, st_off = (OUT_U8 ? 1u : 2u) * (uint32_t)x0;
+    // Border strips (W >= 4, the launcher sees to that): a lane whose four columns hang over the left or right image
+    // border loads the nearest dword that lies inside the row and shifts the outside bytes away -- zeros come in, which
+    // is what an out-of-image pixel has to be (see "Bit-exactness" above).  One load per lane and row as in the
+    // interior, no per-byte loads with 64-bit lane addresses (those were what made this instantiation spill).
+    uint32_t sh_r = 0, sh_l = 0;
+    const bool in_any = xin > -4 && xin < W; // at least one column inside
+    if (COL_EDGE) {
+        const int xc = min(max(xin, 0), W - 4);
+        ld_off = (uint32_t)xc; // from the row's first byte: the offset register is UNSIGNED (xc - C would wrap)
+        if (in_any) {
+            sh_l = (uint32_t)(8 * (xc - xin)) & 31u;     // xin < 0: pixel 0 moves up to byte -xin
+            sh_r = (uint32_t)(8 * (xin - xc)) & 31u;     // xin > W - 4: byte xin - (W - 4) moves down to byte 0
+            if (xin >= 0) sh_l = 0;
+            if (xin <= W - 4) sh_r = 0;
+        }
+    }
 
     auto load_row = [&](int r) -> uint32_t {
         if (ROW_EDGE && (r < 0 || r >= H)) return 0u; // wave-uniform
         const uint8_t *p = jb.fimg + (size_t)r * W; // wave-uniform
         uint32_t v = 0u;
-        if (!COL_EDGE || full4) {
-            asm volatile("" : "+v"(ld_off)); // see ld_off
-            __builtin_memcpy(&v, p + ld_off, 4);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int x = x0 + j;
-                if (x >= 0 && x < W) v |= (uint32_t)p[x] << (8 * j);
-            }
-        }
+        asm volatile("" : "+v"(ld_off)); // see ld_off
+        __builtin_memcpy(&v, p + (COL_EDGE ? 0 : xin - x0) + ld_off, 4);
         return v;
+    };
+    // applied where the row is USED (two rows after the load): shifting at the load would wait for it there
+    auto fix_row = [&](uint32_t v) -> uint32_t {
+        if (!COL_EDGE) return v;
+        v = (v >> sh_r) << sh_l;
+        return in_any ? v : 0u;
     };
 
     float acc[RING][4]; // open column sums; slot = phase of the row that is the output's tap 0
@@ -372,8 +418,9 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[s][i] = 0.0f;
 
-    auto step = [&](auto ph, int r, uint32_t cur) {
+    auto step = [&](auto ph, int r, uint32_t cur_raw) {
         constexpr int PH = decltype(ph)::value; // (r - rfirst) mod RING
+        const uint32_t cur = fix_row(cur_raw);
         // ---- row pass of input row r ----------------------------------------------------------------
         float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (!ROW_EDGE || (r >= 0 && r < H)) {
@@ -393,6 +440,47 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 #pragma unroll
                     for (int a = 0; a <= C; a++) Q[i][a] = __fmul_rn(v[i], T[a]);
             }
+            if constexpr (SYS) {
+                constexpr int NL = SysCfg<C>::NL;
+                // ch[j]: the sum whose first term is pixel j of the lane it started in; after t hand-overs pixel e of
+                // the lane it is in is its tap k = e - j + 4t.  As above the DPP instructions are kept in runs.
+                float ch[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { // stage 0 (plain): open the four sums that start here
+                    ch[j] = Q[j][C];
+#pragma unroll
+                    for (int e = j + 1; e < 4 && e - j <= 2 * C; e++) {
+                        const int k = e - j;
+                        ch[j] = __fadd_rn(ch[j], Q[e][k < C ? C - k : k - C]);
+                    }
+                    if ((j + 2 * C) / 4 == 0) res[(j + 2 * C) % 4] = ch[j]; // window 3: pixels j .. j+2 are all mine
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 1; tt <= NL; tt++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { // (DPP) take the sum over from the left with my pixel 0 added
+                        const int k = 4 * tt - j;
+                        if (tt > (j + 2 * C) / 4) continue; // finished in an earlier lane
+                        ch[j] = __fadd_rn(lane_shr1(ch[j]), Q[0][k < C ? C - k : k - C]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { // (plain) my other pixels
+                        if (tt > (j + 2 * C) / 4) continue;
+#pragma unroll
+                        for (int e = 1; e < 4; e++) {
+                            const int k = e - j + 4 * tt;
+                            if (k > 2 * C) continue;
+                            ch[j] = __fadd_rn(ch[j], Q[e][k < C ? C - k : k - C]);
+                        }
+                        if (tt == (j + 2 * C) / 4) // its last term was one of mine: output (j + 2C) mod 4 of this lane
+                            res[(j + 2 * C) % 4] = ch[j];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                row_quot(res);
+            } else {
             // The leading terms of output i -- the pixels left of this lane -- are summed by the LEFT neighbour
             // (same operands, same order, so the same bits) and arrive as one value whose wave shift folds into
             // the next add: every lane therefore computes pre[i] for its right neighbour.  Without this each of the
@@ -472,7 +560,9 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) res[i] = FMA_DIV ? __fmaf_rn(sum[i], fma_c, sum[i]) : div_by(sum[i], cnt_h[i], inv_h[i]);
+            for (int i = 0; i < 4; i++) res[i] = sum[i];
+            row_quot(res);
+            }
         }
 
         // ---- column pass: row r is tap k of output row r + C - k --------------------------------------
@@ -578,7 +668,7 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 
 // Live state per lane: 4(2C+1) open sums + 4(C+1) products + ~30; without an occupancy target the scheduler
 // interleaves several rows' products and doubles that.
-template <int C, bool USE_LUT, bool OUT_U8 = false>
+template <int C, bool USE_LUT, bool OUT_U8 = false, bool SYS = false>
 // (6 waves per SIMD spill: 2.05 ms against 1.05; 4 compile to the same code as 5 -- profiles/r02/ab4_*.txt)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 5 ? 5 : 4)))
 void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, int H, int W, int n_strips,
@@ -593,6 +683,9 @@ void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, i
         __syncthreads();
     }
     const float *lut = lut_mem;
+    // per-lane column-border weights (border strips only, see gauss_sym_strip)
+    __shared__ __attribute__((aligned(16))) float wts_mem[256 * 8];
+    float *wts = wts_mem + threadIdx.x * 8;
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
     if (wave >= total_waves) return;
@@ -606,27 +699,29 @@ void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, i
     jb.W = W;
     jb.ybeg = g * seg_rows;
     jb.yend = min(H, jb.ybeg + seg_rows);
-    jb.x0 = s * K::SW + (lane - K::HL) * 4; // first of this lane's 4 columns (halo lanes may be outside)
+    constexpr int SW = SYS ? SysCfg<C>::SW : K::SW, LEFT = SYS ? SysCfg<C>::NL : K::HL;
+    jb.x0 = s * SW + (lane - LEFT) * 4; // first of this lane's 4 output columns (halo lanes may be outside)
     jb.fimg = img + (size_t)f * H * W;
     jb.fout = (int16_t *)out + (size_t)f * H * W;
     jb.fout8 = (uint8_t *)out + (size_t)f * H * W;
 
-    // the strip's lanes span columns [s*SW - 4HL, s*SW + SW + 4HL)
-    const bool col_edge = (s * K::SW - 4 * K::HL < 0) || (s * K::SW + K::SW + 4 * K::HL > W);
+    // the strip's lanes load columns [s*SW - 4HL, s*SW + SW + 4HL); systolic: [s*SW - 4NL + C, s*SW + SW + C)
+    const bool col_edge = SYS ? (s * SW - 4 * LEFT + C < 0) || (s * SW + SW + C > W)
+                              : (s * SW - 4 * LEFT < 0) || (s * SW + SW + 4 * LEFT > W);
     // rows loaded: ybeg-C .. yend-1+C, up to 2C more for the rounding to whole loop trips, +2 prefetched
     const bool row_edge = (jb.ybeg - C < 0) || (jb.yend + C + K::RING >= H);
     if (col_edge) {
         if (row_edge)
-            gauss_sym_strip<C, true, true, false, USE_LUT, OUT_U8>(jb, t, lut);
+            gauss_sym_strip<C, true, true, false, USE_LUT, OUT_U8, SYS>(jb, t, lut, wts);
         else
-            gauss_sym_strip<C, true, false, false, USE_LUT, OUT_U8>(jb, t, lut);
+            gauss_sym_strip<C, true, false, false, USE_LUT, OUT_U8, SYS>(jb, t, lut, wts);
     } else {
         if (row_edge)
-            gauss_sym_strip<C, false, true, false, USE_LUT, OUT_U8>(jb, t, lut);
+            gauss_sym_strip<C, false, true, false, USE_LUT, OUT_U8, SYS>(jb, t, lut, wts);
         else if (use_fma_div)
-            gauss_sym_strip<C, false, false, true, USE_LUT, OUT_U8>(jb, t, lut, fma_c);
+            gauss_sym_strip<C, false, false, true, USE_LUT, OUT_U8, SYS>(jb, t, lut, wts, fma_c);
         else
-            gauss_sym_strip<C, false, false, false, USE_LUT, OUT_U8>(jb, t, lut);
+            gauss_sym_strip<C, false, false, false, USE_LUT, OUT_U8, SYS>(jb, t, lut, wts);
     }
 }
 
@@ -705,8 +800,9 @@ int gaussian_fma_div_table(const unsigned (**table)[2])
 
 static bool fma_div_enabled = true; // A/B switch (canny_hip_ctx_set_option "gaussian_fma_div")
 void gaussian_set_fma_div(bool on) { fma_div_enabled = on; }
-// A/B switch "tune_gaussian_variant": 0 = symmetric-tap kernel with the row-pass products looked up in an LDS
-// table (default), 1 = LDS ring kernel, 2 = symmetric-tap kernel that multiplies
+// A/B switch "tune_gaussian_variant": 0 = symmetric-tap kernel, systolic row pass, products looked up in an LDS
+// table (default), 1 = LDS ring kernel, 2 = symmetric-tap kernel that multiplies and fetches products (round 1),
+// 3 = product-fetching row pass with the table (rounds 2-3 default), 4 = systolic row pass that multiplies
 static int march_variant = 0;
 void gaussian_set_march_variant(int v) { march_variant = v; }
 static int tune_seg_target = 0; // A/B switch "tune_gaussian_seg": approximate rows per wave segment, 0 = automatic
@@ -751,11 +847,14 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
                                  const GaussTaps &taps, hipStream_t stream, int out_u8)
 {
     using K = MarchCfg<C>;
-    int n_strips = (width + K::SW - 1) / K::SW;
+    if (width < 4) return hipErrorInvalidValue; // the border strips load whole dwords inside a row
     // the symmetric-tap kernel needs tap[C-a] == tap[C+a] bit for bit (true for the reference's taps)
     bool symmetric = march_variant != 1;
     for (int a = 1; a <= C && symmetric; a++)
         symmetric = std::memcmp(&taps.tap[C - a], &taps.tap[C + a], sizeof(float)) == 0;
+    const bool systolic = symmetric && (march_variant == 0 || march_variant == 4);
+    const int strip_w = systolic ? SysCfg<C>::SW : K::SW;
+    int n_strips = (width + strip_w - 1) / strip_w;
     // longest segments that still give the chip a few thousand waves; the symmetric kernel processes
     // rows in trips of 2C+1, so its segments are sized to make seg + 2C a whole number of trips
     auto seg_for = [&](int target) {
@@ -822,28 +921,35 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
             use_fma = 1;
             std::memcpy(&fma_c, &e[1], sizeof(fma_c));
         }
-    if (out_u8 && !(symmetric && march_variant == 0)) return hipErrorNotSupported;
-    if (out_u8)
-        hipLaunchKernelGGL((gauss_sym_kernel<C, true, true>), dim3(blocks), dim3(256), 0, stream, img, out, height,
-                           width, n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
-    else if (symmetric && march_variant == 0)
-        hipLaunchKernelGGL((gauss_sym_kernel<C, true>), dim3(blocks), dim3(256), 0, stream, img, out, height, width,
-                           n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
-    else if (symmetric)
-        hipLaunchKernelGGL((gauss_sym_kernel<C, false>), dim3(blocks), dim3(256), 0, stream, img, out, height, width,
-                           n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
-    else
+    const bool table = march_variant == 0 || march_variant == 3;
+    if (out_u8 && !(symmetric && table)) return hipErrorNotSupported;
+#define CANNY_LAUNCH_SYM(LUT, U8, SYS)                                                                                  \
+    hipLaunchKernelGGL((gauss_sym_kernel<C, LUT, U8, SYS>), dim3(blocks), dim3(256), 0, stream, img, out, height,     \
+                       width, n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c)
+    if (symmetric && table && out_u8) {
+        if (systolic) CANNY_LAUNCH_SYM(true, true, true); else CANNY_LAUNCH_SYM(true, true, false);
+    } else if (symmetric && table) {
+        if (systolic) CANNY_LAUNCH_SYM(true, false, true); else CANNY_LAUNCH_SYM(true, false, false);
+    } else if (symmetric) {
+        if (systolic) CANNY_LAUNCH_SYM(false, false, true); else CANNY_LAUNCH_SYM(false, false, false);
+    } else {
         hipLaunchKernelGGL(gauss_march_kernel<C>, dim3(blocks), dim3(K::WPB * 64), 0, stream, img, (int16_t *)out,
                            height, width, n_strips, n_segs, seg, (int)waves, taps, use_fma, fma_c);
+    }
+#undef CANNY_LAUNCH_SYM
     return hipGetLastError();
 }
 
-bool gaussian_march_supported(int center, int, int) { return center >= 1 && center <= 8; }
+// (width >= 4: the border strips load whole dwords that must lie inside the row; narrower images take the generic path)
+bool gaussian_march_supported(int center, int, int width) { return center >= 1 && center <= 8 && width >= 4; }
 
 static hipError_t launch_march_any(const uint8_t *img, void *out, int height, int width, int n_frames,
                                    const GaussTaps &taps, hipStream_t stream, int out_u8)
 {
     switch (taps.center) {
+#ifdef CANNY_GAUSS_ONLY_C // development aid: compile one window only (-DCANNY_GAUSS_ONLY_C=5) to read its ISA quickly
+    case CANNY_GAUSS_ONLY_C: return launch_march_c<CANNY_GAUSS_ONLY_C>(img, out, height, width, n_frames, taps, stream, out_u8);
+#else
     case 1: return launch_march_c<1>(img, out, height, width, n_frames, taps, stream, out_u8);
     case 2: return launch_march_c<2>(img, out, height, width, n_frames, taps, stream, out_u8);
     case 3: return launch_march_c<3>(img, out, height, width, n_frames, taps, stream, out_u8);
@@ -852,6 +958,7 @@ static hipError_t launch_march_any(const uint8_t *img, void *out, int height, in
     case 6: return launch_march_c<6>(img, out, height, width, n_frames, taps, stream, out_u8);
     case 7: return launch_march_c<7>(img, out, height, width, n_frames, taps, stream, out_u8);
     case 8: return launch_march_c<8>(img, out, height, width, n_frames, taps, stream, out_u8);
+#endif
     default: return hipErrorNotSupported;
     }
 }
@@ -864,7 +971,7 @@ hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, i
 
 bool gaussian_march_u8_supported(const GaussTaps &taps)
 {
-    if (taps.center < 1 || taps.center > 8 || march_variant != 0) return false;
+    if (taps.center < 1 || taps.center > 8 || (march_variant != 0 && march_variant != 3)) return false;
     for (int a = 1; a <= taps.center; a++)
         if (std::memcmp(&taps.tap[taps.center - a], &taps.tap[taps.center + a], sizeof(float)) != 0) return false;
     return true;

@@ -93,7 +93,7 @@ void canny_hip_ctx_destroy(canny_hip_ctx *ctx);
 int canny_hip_ctx_set_stream(canny_hip_ctx *ctx, void *hip_stream);
 int canny_hip_ctx_device(const canny_hip_ctx *ctx);
 /* Kernel-path selection, for A/B measurements and tests; every path gives identical results.
- *   "gaussian_path":  0 auto (default), 1 generic two-pass, 2 wave-marching (window <= 17)
+ *   "gaussian_path":  0 auto (default), 1 generic two-pass, 2 wave-marching (window <= 17 and width >= 4)
  *   "sobel_nms_path": 0 auto (default), 1 LDS-tiled, 2 wave-marching
  *   "gaussian_fma_div": 1 (default) / 0 -- single-fma division by the full-window weight (process-wide)
  *   "fuse_classify": 1 (default) / 0 -- canny(): the Sobel+NMS kernel writes the hysteresis bit-planes itself
@@ -256,7 +256,8 @@ int canny_hip_dev_sobel_nms(canny_hip_ctx *ctx, const short *d_smoothed, int hei
                             short *d_nms);
 /* The two kernels of canny()'s "smoothed_u8" path on their own (tests, A/B): the Gaussian storing bytes
  * and the fused Sobel+NMS reading them (3 algorithmic bytes per pixel).
- * CANNY_HIP_ERR_UNSUPPORTED where the marching kernels do not apply (window > 17, asymmetric taps, A/B variants). */
+ * CANNY_HIP_ERR_UNSUPPORTED where the marching kernels do not apply (window > 17, width < 4, asymmetric taps, A/B
+ * variants). */
 int canny_hip_dev_gaussian_u8(canny_hip_ctx *ctx, const unsigned char *d_img, float sigma, int height, int width,
                               int n_frames, unsigned char *d_result);
 int canny_hip_dev_sobel_nms_u8in(canny_hip_ctx *ctx, const unsigned char *d_smoothed, int height, int width,

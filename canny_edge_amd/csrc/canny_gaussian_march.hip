@@ -303,6 +303,10 @@ __device__ __forceinline__ void for_each_phase(F &&f, std::integer_sequence<int,
 // sum_j floor((j+2C)/4) cross a lane (window 11: 40 adds, 10 of them DPP) where the product-fetching form above needs
 // 44 with 19 DPP; every add has the reference's operands in the reference's order, whichever lane executes it.  The
 // halo is on the left only (SysCfg::NL lanes), and the loads sit C bytes right of the (dword aligned) stores.
+#ifndef GAUSS_ROTATE_LOOKUPS
+#define GAUSS_ROTATE_LOOKUPS 1
+#endif
+
 template <int C>
 struct SysCfg {
     static constexpr int NL = (3 + 2 * C) / 4;       // lanes a sum crosses at most = halo lanes (all on the left)
@@ -328,7 +332,9 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
         // The multiplying variant keeps the taps in VGPRs: a multiply with an SGPR operand is a slow-class instruction
         // (tools/valu_issue_bench.hip) and that variant does 2(C+1) of them per value: 1.180 -> 1.086 ms per
         // 128 x 4K together with the phased row pass.  The table variant multiplies only in the column pass and
-        // needs the six registers more: pinning them there costs a wave per SIMD (1.11 -> 1.25 ms).
+        // needs the six registers more: pinning them there cost a wave per SIMD in round 2 (1.11 -> 1.25 ms), and in
+        // the systolic form, where four or (with two prologue spills) all six fit, it buys nothing: 0.886 / 0.888
+        // against 0.869 ms (profiles/r03/ab13_*.txt).
         if (!USE_LUT) asm volatile("" : "+v"(T[a]));
     }
 
@@ -418,28 +424,40 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[s][i] = 0.0f;
 
-    auto step = [&](auto ph, int r, uint32_t cur_raw) {
+    // ROT (systolic row pass with the product table): the products of row r+1 are looked up BETWEEN the row pass and
+    // the column pass of row r -- their registers are free then, and the table's latency (and its bank conflicts) pass
+    // under the ~70 instructions of the column pass instead of in front of the next row pass.  Rows outside the image
+    // arrive as zero bytes, whose products are the table's exact zeros, so the look-ups need no row test.
+    // (Not in the border strips: with their shift amounts and weight slot the 24 products alive across the column pass
+    // no longer fit the registers of five waves per SIMD.)
+    constexpr bool ROT = SYS && USE_LUT && GAUSS_ROTATE_LOOKUPS && !COL_EDGE;
+    float Q[4][C + 1]; // products of the row the next row pass works on
+    auto products = [&](uint32_t cur) {
+        if (USE_LUT) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float *row = lut + ((cur >> (8 * i)) & 0xffu);
+#pragma unroll
+                for (int a = 0; a <= C; a++) Q[i][a] = row[a * 256];
+            }
+        } else {
+            const float v[4] = {(float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
+                                (float)(cur >> 24)};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int a = 0; a <= C; a++) Q[i][a] = __fmul_rn(v[i], T[a]);
+        }
+    };
+
+    auto step = [&](auto ph, int r, uint32_t cur_raw, uint32_t next_raw) {
         constexpr int PH = decltype(ph)::value; // (r - rfirst) mod RING
-        const uint32_t cur = fix_row(cur_raw);
         // ---- row pass of input row r ----------------------------------------------------------------
         float res[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!ROT) {
+            if (!ROW_EDGE || (r >= 0 && r < H)) products(fix_row(cur_raw));
+        }
         if (!ROW_EDGE || (r >= 0 && r < H)) {
-            float Q[4][C + 1];
-            if (USE_LUT) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float *row = lut + ((cur >> (8 * i)) & 0xffu);
-#pragma unroll
-                    for (int a = 0; a <= C; a++) Q[i][a] = row[a * 256];
-                }
-            } else {
-                const float v[4] = {(float)(cur & 0xffu), (float)((cur >> 8) & 0xffu), (float)((cur >> 16) & 0xffu),
-                                    (float)(cur >> 24)};
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int a = 0; a <= C; a++) Q[i][a] = __fmul_rn(v[i], T[a]);
-            }
             if constexpr (SYS) {
                 constexpr int NL = SysCfg<C>::NL;
                 // ch[j]: the sum whose first term is pixel j of the lane it started in; after t hand-overs pixel e of
@@ -565,6 +583,11 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
             }
         }
 
+        if (ROT) {
+            __builtin_amdgcn_sched_barrier(0);
+            products(fix_row(next_raw));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- column pass: row r is tap k of output row r + C - k --------------------------------------
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -648,15 +671,21 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
     const int rfirst = ybeg - C;
     const int rows = yend - ybeg + 2 * C;
     const int rlast = rfirst + RING * ((rows + RING - 1) / RING) - 1;
+    // (ROT: three rows ahead -- the look-ups need a row half a step earlier)
+    constexpr int AHEAD = ROT ? 3 : 2;
     uint32_t pf[RING];
     pf[0] = load_row(rfirst);
     pf[1] = load_row(rfirst + 1);
+    if (ROT) {
+        pf[2] = load_row(rfirst + 2);
+        products(fix_row(pf[0]));
+    }
     for (int r = rfirst; r <= rlast; r += RING) {
         for_each_phase(
             [&](auto ph) {
                 constexpr int PH = decltype(ph)::value;
-                pf[(PH + 2) % RING] = load_row(r + PH + 2);
-                step(ph, r + PH, pf[PH]);
+                pf[(PH + AHEAD) % RING] = load_row(r + PH + AHEAD);
+                step(ph, r + PH, pf[PH], pf[(PH + 1) % RING]);
                 // keep the scheduler from interleaving rows: one row's products are all the registers allow
                 __builtin_amdgcn_sched_barrier(0);
             },
@@ -709,7 +738,7 @@ void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, i
     const bool col_edge = SYS ? (s * SW - 4 * LEFT + C < 0) || (s * SW + SW + C > W)
                               : (s * SW - 4 * LEFT < 0) || (s * SW + SW + 4 * LEFT > W);
     // rows loaded: ybeg-C .. yend-1+C, up to 2C more for the rounding to whole loop trips, +2 prefetched
-    const bool row_edge = (jb.ybeg - C < 0) || (jb.yend + C + K::RING >= H);
+    const bool row_edge = (jb.ybeg - C < 0) || (jb.yend + C + K::RING + 1 >= H); // (+3 with rotated look-ups)
     if (col_edge) {
         if (row_edge)
             gauss_sym_strip<C, true, true, false, USE_LUT, OUT_U8, SYS>(jb, t, lut, wts);

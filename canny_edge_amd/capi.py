@@ -49,6 +49,7 @@ EXPORTS = (
     "canny_hip_dev_gaussian_u8", "canny_hip_dev_sobel_nms_u8in", "canny_hip_host_register", "canny_hip_host_unregister",
     "canny_hip_canny_batch_bits", "canny_hip_canny_multi_gpu_bits", "canny_hip_dev_canny_bits",
     "canny_hip_probe_copy", "canny_hip_ctx_get_option", "canny_hip_selftest_expand_bits",
+    "canny_hip_selftest_march_order",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -135,6 +136,7 @@ def load() -> C.CDLL:
         "canny_hip_probe_copy": ([p, p, p, C.c_size_t, i, C.POINTER(C.c_double)], i),
         "canny_hip_ctx_get_option": ([p, C.c_char_p, ip], i),
         "canny_hip_selftest_expand_bits": ([p, i, i, i, p, i], i),
+        "canny_hip_selftest_march_order": ([i, i, p], i),
         "canny_hip_selftest_mag_angle": ([p, i, p, p], i),
         "canny_hip_selftest_div": ([p, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
         "canny_hip_selftest_div_fma": ([p, f, f, C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)], i),
@@ -169,6 +171,15 @@ def expand_bits(bits: np.ndarray, height: int, width: int, u8: bool = False, thr
                                                out.ctypes.data_as(C.c_void_p), threads)
     if st:
         raise CannyHipError(st, "selftest_expand_bits")
+    return out
+
+
+def march_order(n_segs: int, n_strips: int) -> np.ndarray:
+    """Host-only: the (segment, strip) cell each wave index of a marching launch takes within a frame (border first)."""
+    out = np.empty((n_segs * n_strips, 2), np.int32)
+    st = load().canny_hip_selftest_march_order(n_segs, n_strips, out.ctypes.data_as(C.c_void_p))
+    if st:
+        raise CannyHipError(st, "selftest_march_order")
     return out
 
 

@@ -2070,6 +2070,18 @@ int canny_hip_probe_copy(canny_hip_ctx *ctx, const void *d_src, void *d_dst, siz
     return CANNY_HIP_OK;
 }
 
+// Host-only: the cell order of the marching launches (march_cell_of), for the bijectivity test.
+int canny_hip_selftest_march_order(int n_segs, int n_strips, int *out_pairs)
+{
+    if (!out_pairs || n_segs < 1 || n_strips < 1 || (long long)n_segs * n_strips > (1 << 24)) return CANNY_HIP_ERR_INVALID;
+    for (int k = 0; k < n_segs * n_strips; k++) {
+        const MarchCell c = march_cell_of(k, n_segs, n_strips);
+        out_pairs[2 * k] = c.seg;
+        out_pairs[2 * k + 1] = c.strip;
+    }
+    return CANNY_HIP_OK;
+}
+
 // Host-only: the batch pipelines' bit-map expansion (ExpandPool) on a caller-supplied bit map; needs no device.
 int canny_hip_selftest_expand_bits(const unsigned char *bits, int height, int width, int to_u8, void *out, int n_threads)
 {

@@ -719,9 +719,9 @@ void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, i
     const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform
     if (wave >= total_waves) return;
 
-    const int s = wave % n_strips;
-    const int g = (wave / n_strips) % n_segs;
     const int f = wave / (n_strips * n_segs);
+    const MarchCell cell = march_cell_of(wave - f * (n_strips * n_segs), n_segs, n_strips); // border cells first
+    const int s = cell.strip, g = cell.seg;
     GaussJob jb;
     jb.lane = lane;
     jb.H = H;

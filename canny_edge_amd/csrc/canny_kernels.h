@@ -19,6 +19,45 @@ struct GaussTaps {
     float tap[kMaxWindow];
 };
 
+// Order in which the waves of a marching launch take the (segment, strip) cells of a frame: the frame's BORDER cells
+// first (top and bottom segments, then the first and last strip of the segments in between), the interior cells after
+// them.  Border cells run the border instantiations, which cost 1.1-1.7 x an interior cell; waves are dealt to SIMD
+// slots in index order, so with the plain row-major order the last waves of a launch -- the bottom segment of the last
+// frame -- were its most expensive ones and the chip waited for them with most slots empty.  Frames stay contiguous
+// (and so do the interior cells of a frame, which share halo rows and columns in L2).  Bijective on [0, n_segs*n_strips).
+struct MarchCell {
+    int seg, strip;
+};
+__host__ __device__ inline MarchCell march_cell_of(int k, int n_segs, int n_strips)
+{
+    MarchCell c;
+#ifdef CANNY_MARCH_ROW_MAJOR // A/B builds only: the plain order
+    n_segs = 0;
+#endif
+    if (n_segs < 3 || n_strips < 3) { // every cell is a border cell
+        c.seg = k / n_strips;
+        c.strip = k % n_strips;
+        return c;
+    }
+    const int sides = 2 * (n_segs - 2);
+    if (k < n_strips) {
+        c.seg = 0;
+        c.strip = k;
+    } else if (k < 2 * n_strips) {
+        c.seg = n_segs - 1;
+        c.strip = k - n_strips;
+    } else if (k < 2 * n_strips + sides) {
+        const int kk = k - 2 * n_strips;
+        c.seg = 1 + (kk >> 1);
+        c.strip = (kk & 1) ? n_strips - 1 : 0;
+    } else {
+        const int kk = k - 2 * n_strips - sides;
+        c.seg = 1 + kk / (n_strips - 2);
+        c.strip = 1 + kk % (n_strips - 2);
+    }
+    return c;
+}
+
 // Geometry of the hysteresis bit-planes: per frame tiles_y x tiles_x tiles, each 64 words (one
 // 64-bit word = 64 consecutive pixels of one row), stored tile-major so that one wave reads a
 // whole tile with one coalesced 512-byte load.

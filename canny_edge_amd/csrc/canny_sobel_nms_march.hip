@@ -867,9 +867,9 @@ void sobel_nms_march_kernel(const void *__restrict__ in,
     }
     const int wave = __builtin_amdgcn_readfirstlane(bid * SNM_WPB + (threadIdx.x >> 6));
     if (wave >= total_waves) return;
-    const int s = wave % n_strips;
-    const int g = (wave / n_strips) % n_segs;
     const int f = wave / (n_strips * n_segs);
+    const MarchCell cell = march_cell_of(wave - f * (n_strips * n_segs), n_segs, n_strips); // border cells first
+    const int s = cell.strip, g = cell.seg;
     StripJob jb;
     jb.lane = threadIdx.x & 63;
     jb.H = H;

@@ -330,6 +330,10 @@ int canny_hip_selftest_div_fma_table(int index, float *divisor, float *c);
  * padded to bytes: height * ((width + 7) / 8) bytes) becomes the reference's short plane (0 / 255), or with to_u8 != 0 a
  * byte plane, written by n_threads pool threads exactly as canny_hip_canny_batch does it. */
 int canny_hip_selftest_expand_bits(const unsigned char *bits, int height, int width, int to_u8, void *out, int n_threads);
+/* Host-only: the order in which the waves of a marching launch (Gaussian, Sobel+NMS) take the n_segs x n_strips cells
+ * of a frame -- border cells first, see march_cell_of in csrc/canny_kernels.h.  Writes n_segs * n_strips (segment, strip)
+ * pairs to out_pairs. */
+int canny_hip_selftest_march_order(int n_segs, int n_strips, int *out_pairs);
 /* Host-only: number of CPUs in a sysfs-style list ("0-3,8,10-11" -> 7; 0 if malformed) -- the parser behind the
  * sharder's NUMA binding. */
 int canny_hip_selftest_cpulist_count(const char *text);

@@ -169,3 +169,21 @@ def test_bit_map_expansion_of_the_compact_transfer(shape, u8):
     out = backing[3:3 + h * w].reshape(h, w)
     capi.expand_bits(bits, h, w, u8=u8, threads=3, out=out)
     assert np.array_equal(out, want) and (backing[:3] == 77).all() and (backing[3 + h * w:] == 77).all()
+
+
+def test_march_cell_order_is_a_bijection_with_the_border_first():
+    """Host-only: the order in which marching waves take a frame's (segment, strip) cells (csrc/canny_kernels.h
+    march_cell_of) covers every cell exactly once and puts the border cells -- the expensive instantiations -- first."""
+    from canny_edge_amd import capi
+    for n_segs, n_strips in [(1, 1), (1, 7), (7, 1), (2, 2), (2, 9), (9, 2), (3, 3), (15, 16), (36, 9), (5, 4), (100, 3)]:
+        cells = capi.march_order(n_segs, n_strips)
+        assert cells.shape == (n_segs * n_strips, 2)
+        assert len({(int(g), int(s)) for g, s in cells}) == n_segs * n_strips
+        assert cells[:, 0].min() == 0 and cells[:, 0].max() == n_segs - 1
+        assert cells[:, 1].min() == 0 and cells[:, 1].max() == n_strips - 1
+        border = (cells[:, 0] == 0) | (cells[:, 0] == n_segs - 1) | (cells[:, 1] == 0) | (cells[:, 1] == n_strips - 1)
+        n_border = int(border.sum())
+        assert border[:n_border].all() and not border[n_border:].any()
+        if n_segs >= 3 and n_strips >= 3:  # interior cells stay row-major (neighbours share halo rows and columns)
+            inner = cells[n_border:]
+            assert np.array_equal(inner, np.array([(g, s) for g in range(1, n_segs - 1) for s in range(1, n_strips - 1)]))

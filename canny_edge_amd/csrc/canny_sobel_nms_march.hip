@@ -119,6 +119,9 @@ using IC = std::integral_constant<int, N>;
 #ifndef FLT_GROUP
 #define FLT_GROUP 2
 #endif
+#ifndef FLT_DEFER_STORE
+#define FLT_DEFER_STORE 1 // a row's output pixels are stored at the top of the NEXT row's step (see march_strip; 0: at once, for A/B)
+#endif
 #ifndef FLT_CARRIERS
 #define FLT_CARRIERS 1 // 1: one v_perm_b32-packed bin carrier per pixel; 2: the two floats themselves
 #endif
@@ -304,6 +307,26 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
 
+    // DEFER: a row's output pixels are parked in NP registers and stored at the TOP of the next row's step, right
+    // behind that step's wait for its input row.  The counter of that wait (vmcnt) counts stores as well as loads: a
+    // store issued at the end of a row was waited for -- acknowledged by memory -- a few instructions later at the top
+    // of the next row, every row; issued behind the wait it has a whole row's time.  (The table-fed kernels also hide
+    // their LDS read this way.)
+    constexpr bool DEFER = FLT_DEFER_STORE != 0;
+    uint32_t pend[NP] = {};
+    int pend_y = -1; // wave-uniform: the parked row, -1 = none
+    auto park = [&](const uint32_t (&outp)[NP], int y) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) pend[q] = outp[q];
+        pend_y = __builtin_amdgcn_readfirstlane(y);
+    };
+    auto store_pending = [&]() {
+        if (DEFER && pend_y >= 0) {
+            if (owner) store_row<NP>(jb.fout + (size_t)pend_y * W + x0, pend);
+            pend_y = -1;
+        }
+    };
+
     // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
     auto step = [&](auto ph, int r, const uint32_t (&praw)[NP]) {
         constexpr int PH = decltype(ph)::value;
@@ -317,6 +340,13 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
         } else {
 #pragma unroll
             for (int i = 0; i < NP; i++) p[i] = praw[i];
+        }
+        if (DEFER) { // the row's pixels have arrived (pinned: the wait stays in front of the store)
+#pragma unroll
+            for (int i = 0; i < NP; i++) asm volatile("" : "+v"(p[i]));
+            __builtin_amdgcn_sched_barrier(0);
+            store_pending();
+            __builtin_amdgcn_sched_barrier(0);
         }
         constexpr int k2 = PH % 3, k1 = (PH + 2) % 3, k0 = (PH + 1) % 3; // d/t of rows r, r-1, r-2
         constexpr int m2 = PH % 3, m1 = (PH + 2) % 3, m0 = (PH + 1) % 3; // M and bins of rows r-1, r-2, r-3
@@ -451,7 +481,10 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                     const unsigned rowoff = (unsigned)(y2 - ybeg) * kStagePitch;
                     stage[rowoff + stage_col] = (uint8_t)cbits; // halo lanes write pad columns nobody reads
                     stage[kStagePlane + rowoff + stage_col] = (uint8_t)sb;
-                    if (owner) store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
+                    if (DEFER)
+                        park(outp, y2);
+                    else if (owner)
+                        store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                 } else if (owner) { // W % 8 == 0: an owner lane's pixels are all inside the image
                     if (NP == 4 || (jb.lane & 1)) {
                         const unsigned bx = (unsigned)x0 >> 3;
@@ -462,6 +495,8 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                     }
                     store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                 }
+            } else if (DEFER && !COL_EDGE) {
+                park(outp, y2); // interior strips: every owner lane stores whole rows
             } else if (owner) {
                 int16_t *dst = jb.fout + (size_t)y2 * W + x0;
                 if (!COL_EDGE || full8) {
@@ -491,6 +526,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
         load_row(r + 4, pb);
         step(IC<2>{}, r + 2, pc);
     }
+    store_pending();
     // Every row below yend has been staged by now; the row loop's state is dead here, so the flush's own
     // registers come for free (called from inside the loop it pushed the kernel from 160 to 215 VGPRs).
     if (STAGE) stage_flush_segment();
@@ -660,6 +696,22 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
 
+    // DEFER: see march_strip -- a row's output pixels are parked and stored at the top of the next row's step.
+    constexpr bool DEFER = FLT_DEFER_STORE != 0;
+    uint32_t pend[NP] = {};
+    int pend_y = -1; // wave-uniform: the parked row, -1 = none
+    auto park = [&](const uint32_t (&outp)[NP], int y) {
+#pragma unroll
+        for (int q = 0; q < NP; q++) pend[q] = outp[q];
+        pend_y = __builtin_amdgcn_readfirstlane(y);
+    };
+    auto store_pending = [&]() {
+        if (DEFER && pend_y >= 0) {
+            if (owner) store_row<NP>(jb.fout + (size_t)pend_y * W + x0, pend);
+            pend_y = -1;
+        }
+    };
+
     // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
     auto step = [&](auto ph, int r, const uint32_t (&praw)[NP]) {
         constexpr int PH = decltype(ph)::value;
@@ -671,6 +723,17 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
         for (int e = 0; e < PX; e++) {
             const uint32_t w = IN_U8 ? praw[e >> 2] >> (8 * (e & 3)) : praw[e >> 1] >> (16 * (e & 1));
             F[k2][e] = (float)(w & 0xffu); // v_cvt_f32_ubyteN
+        }
+        // The previous row's edge-map pixels (DEFER) go out HERE, right behind the wait for this row's pixels: the
+        // counter that wait uses (vmcnt) also counts stores, so a store issued late in a row is waited for at the top
+        // of the next one; issued here it has a whole row's time to be acknowledged.  (The conversions are pinned in
+        // front of it -- sunk behind the store, their wait would cover the row load issued a moment ago as well.)
+        if (DEFER) {
+#pragma unroll
+            for (int e = 0; e < PX; e++) asm volatile("" : "+v"(F[k2][e]));
+            FLT_SCHED_FENCE();
+            store_pending();
+            FLT_SCHED_FENCE();
         }
 
         // ---- gradient, magnitude and bin carriers for row y1 = r-1 -----------------------------------------------
@@ -778,7 +841,10 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
                     const unsigned rowoff = (unsigned)(y2 - ybeg) * kStagePitch;
                     stage[rowoff + stage_col] = (uint8_t)cbits; // halo lanes write pad columns nobody reads
                     stage[kStagePlane + rowoff + stage_col] = (uint8_t)sb;
-                    if (owner) store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
+                    if (DEFER)
+                        park(outp, y2);
+                    else if (owner)
+                        store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                 } else {
                     const uint32_t tb = sb | (sb << 15);
 #pragma unroll
@@ -793,6 +859,10 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
                         store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                     }
                 }
+            } else if (DEFER && !COL_EDGE) {
+#pragma unroll
+                for (int i = 0; i < NP; i++) outp[i] = (uint32_t)keep[2 * i] | ((uint32_t)keep[2 * i + 1] << 16);
+                park(outp, y2); // interior strips: every owner lane stores whole rows
             } else if (owner) {
 #pragma unroll
                 for (int i = 0; i < NP; i++) outp[i] = (uint32_t)keep[2 * i] | ((uint32_t)keep[2 * i + 1] << 16);
@@ -821,6 +891,7 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
         load_row(r + 4, pb);
         step(IC<2>{}, r + 2, pc);
     }
+    store_pending();
     if (STAGE) stage_flush_segment();
 }
 

@@ -444,8 +444,8 @@ def main():
         roofline = roof("sobel_nms_classify_u8in",
                         "fused Sobel+NMS+threshold-classify on the u8 smoothed plane (u8 in; s16 edge map + "
                         "strong/connectable bit-planes out) -- what canny() runs", 3.25, sn_ms, sn_n,
-                        {"limiter": "VALU issue (~35 instructions per pixel) beside an HBM stream that a plain copy "
-                                    "moves 1.3-1.5x faster (copy_probe), see DESIGN.md"})
+                        {"limiter": "VALU issue (30.5 instructions per pixel, ~3.0 SIMD cycles each: PMC) beside an "
+                                    "HBM stream that a plain copy moves 1.2-1.4x faster (copy_probe), see DESIGN.md"})
     elif fused:
         # s16 smoothed in (2 B/px); out: the provisional s16 edge map (2 B/px, completed in place by the propagation
         # sweeps -- there is no finalize pass) and the two 1-bit hysteresis planes (2/8 B/px).  `frac` / `achieved`

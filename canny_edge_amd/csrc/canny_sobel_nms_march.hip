@@ -119,6 +119,9 @@ using IC = std::integral_constant<int, N>;
 #ifndef FLT_GROUP
 #define FLT_GROUP 2
 #endif
+#ifndef FLT_EARLY_RELOAD
+#define FLT_EARLY_RELOAD 1 // f32 strips: a row buffer is reloaded (row r+3) as soon as row r is converted
+#endif
 #ifndef FLT_DEFER_STORE
 #define FLT_DEFER_STORE 1 // a row's output pixels are stored at the top of the NEXT row's step (see march_strip; 0: at once, for A/B)
 #endif
@@ -713,7 +716,7 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
     };
 
     // One input row r; PH = (r - rfirst) mod 3 selects the register roles.
-    auto step = [&](auto ph, int r, const uint32_t (&praw)[NP]) {
+    auto step = [&](auto ph, int r, uint32_t (&praw)[NP]) {
         constexpr int PH = decltype(ph)::value;
         constexpr int k2 = PH % 3, k1 = (PH + 2) % 3, k0 = (PH + 1) % 3; // F of rows r, r-1, r-2
         constexpr int m2 = PH % 3, m1 = (PH + 2) % 3, m0 = (PH + 1) % 3; // M of rows r-1, r-2, r-3; carriers alike
@@ -733,6 +736,14 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
             for (int e = 0; e < PX; e++) asm volatile("" : "+v"(F[k2][e]));
             FLT_SCHED_FENCE();
             store_pending();
+            FLT_SCHED_FENCE();
+        }
+        // EARLY: the row's raw pixels are converted, so their registers can take row r+3 at once -- three rows in
+        // flight with the same three buffers (the plain loop reloads a buffer at the top of the NEXT step: two rows).
+        if (FLT_EARLY_RELOAD) {
+#pragma unroll
+            for (int e = 0; e < PX; e++) asm volatile("" : "+v"(F[k2][e]));
+            load_row(r + 3, praw);
             FLT_SCHED_FENCE();
         }
 
@@ -883,13 +894,22 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
     uint32_t pa[NP], pb[NP], pc[NP];
     load_row(rfirst, pa);
     load_row(rfirst + 1, pb);
-    for (int r = rfirst; r <= rlast; r += 3) {
-        load_row(r + 2, pc);
-        step(IC<0>{}, r, pa);
-        load_row(r + 3, pa);
-        step(IC<1>{}, r + 1, pb);
-        load_row(r + 4, pb);
-        step(IC<2>{}, r + 2, pc);
+    if (FLT_EARLY_RELOAD) {
+        load_row(rfirst + 2, pc);
+        for (int r = rfirst; r <= rlast; r += 3) {
+            step(IC<0>{}, r, pa);
+            step(IC<1>{}, r + 1, pb);
+            step(IC<2>{}, r + 2, pc);
+        }
+    } else {
+        for (int r = rfirst; r <= rlast; r += 3) {
+            load_row(r + 2, pc);
+            step(IC<0>{}, r, pa);
+            load_row(r + 3, pa);
+            step(IC<1>{}, r + 1, pb);
+            load_row(r + 4, pb);
+            step(IC<2>{}, r + 2, pc);
+        }
     }
     store_pending();
     if (STAGE) stage_flush_segment();
@@ -962,8 +982,8 @@ void sobel_nms_march_kernel(const void *__restrict__ in,
     }
     // first strip: column 0 and the out-of-image halo lane; last strip: column W-1 and columns >= W
     const bool col_edge = (s == 0) || ((s + 1) * SnmCfg<NP>::SW + SnmCfg<NP>::PX >= W);
-    // rows touched: ybeg-2 .. (rounded-up last row) + 2 prefetched  <=  yend + 5
-    const bool row_edge = (jb.ybeg < 2) || (jb.yend + 5 >= H);
+    // rows touched: ybeg-2 .. (rounded-up last row) + 2 prefetched  <=  yend + 5 (+ 3: yend + 6 in the f32 strips)
+    const bool row_edge = (jb.ybeg < 2) || (jb.yend + (FLT && FLT_EARLY_RELOAD ? 6 : 5) >= H);
     if constexpr (FLT) {
         static_assert(NP == 4, "the f32 variant processes 8 pixels per lane");
 #ifdef PROBE_VARIANT

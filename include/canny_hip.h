@@ -135,8 +135,11 @@ int canny_hip_ctx_device(const canny_hip_ctx *ctx);
  *       stage kernel --, 1 packed-i16 everywhere, 2 f32 everywhere; same results bit for bit; process-wide
  *   "tune_plane_stores": 0 (default) the fused Sobel+NMS kernel parks a segment's plane bytes in LDS and writes
  *                    them as whole words after its last row, 1 direct byte stores (process-wide)
- *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel with the row-pass product table in LDS,
- *                    1 LDS-ring marching kernel, 2 symmetric-tap kernel that multiplies (process-wide)
+ *   "tune_gaussian_variant": 0 (default) symmetric-tap marching kernel, systolic row pass (the running sums travel
+ *                    between lanes), row-pass products looked up in an LDS table; 1 LDS-ring marching kernel; 2
+ *                    symmetric-tap kernel that multiplies and fetches its neighbours' products; 3 product-fetching row
+ *                    pass with the table (the default of rounds 2-3); 4 systolic row pass that multiplies; same
+ *                    results bit for bit (process-wide)
  *   "tune_gaussian_seg": approximate rows per wave segment of the marching Gaussian, 0 = automatic (process-wide)
  *   "tune_finalize_mode": 0 (default) row-major hysteresis finalize, 1 tile-patch finalize (process-wide)
  *   "profile_stage_mask": bit s set = stage s (CANNY_HIP_STAGE_*) gets an event pair while profiling is enabled;

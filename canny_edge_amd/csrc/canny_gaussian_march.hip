@@ -35,7 +35,28 @@
 #include <cstring>
 #include <type_traits>
 
+// The file is compiled FOUR times (Makefile: -DCANNY_GAUSS_PART=0..3 -> canny_gaussian_march_p<k>.o) so that the eight
+// window instantiations, which dominate the library's build time, compile in parallel: part 0 holds the host-side
+// entry points, the switches and windows 3..9 (half-windows 1..4), part 1 half-windows 5 and 6, part 2 half-window 7,
+// part 3 half-window 8.  Without the macro (tools/gauss_isa.sh) everything is one translation unit.
+#ifndef CANNY_GAUSS_PART
+#define CANNY_GAUSS_PART -1
+#endif
+#define CANNY_GAUSS_HAS_HOST (CANNY_GAUSS_PART <= 0)
+
 namespace canny {
+
+// A/B switches shared by the parts (defined in part 0, set through canny_hip_ctx_set_option)
+extern bool g_gauss_fma_div_enabled;
+extern int g_gauss_march_variant;
+extern int g_gauss_seg_target;
+// launchers of the half-windows that live in parts 1..3
+hipError_t launch_gauss_march_part1(int center, const uint8_t *img, void *out, int height, int width, int n_frames,
+                                    const GaussTaps &taps, hipStream_t stream, int out_u8);
+hipError_t launch_gauss_march_part2(int center, const uint8_t *img, void *out, int height, int width, int n_frames,
+                                    const GaussTaps &taps, hipStream_t stream, int out_u8);
+hipError_t launch_gauss_march_part3(int center, const uint8_t *img, void *out, int height, int width, int n_frames,
+                                    const GaussTaps &taps, hipStream_t stream, int out_u8);
 
 namespace {
 
@@ -821,22 +842,25 @@ static const unsigned kFmaDivTable[][2] = {
     {0x3f7ffffcu, 0x34800002u}, // S = 1 - 2^-22        c = 2^-22 + 2^-44
 };
 
+#if CANNY_GAUSS_HAS_HOST
 int gaussian_fma_div_table(const unsigned (**table)[2])
 {
     *table = kFmaDivTable;
     return (int)(sizeof(kFmaDivTable) / sizeof(kFmaDivTable[0]));
 }
 
-static bool fma_div_enabled = true; // A/B switch (canny_hip_ctx_set_option "gaussian_fma_div")
-void gaussian_set_fma_div(bool on) { fma_div_enabled = on; }
+bool g_gauss_fma_div_enabled = true; // A/B switch (canny_hip_ctx_set_option "gaussian_fma_div")
+void gaussian_set_fma_div(bool on) { g_gauss_fma_div_enabled = on; }
 // A/B switch "tune_gaussian_variant": 0 = symmetric-tap kernel, systolic row pass, products looked up in an LDS
 // table (default), 1 = LDS ring kernel, 2 = symmetric-tap kernel that multiplies and fetches products (round 1),
 // 3 = product-fetching row pass with the table (rounds 2-3 default), 4 = systolic row pass that multiplies
-static int march_variant = 0;
-void gaussian_set_march_variant(int v) { march_variant = v; }
-static int tune_seg_target = 0; // A/B switch "tune_gaussian_seg": approximate rows per wave segment, 0 = automatic
-void gaussian_set_seg_target(int rows) { tune_seg_target = rows; }
+int g_gauss_march_variant = 0;
+void gaussian_set_march_variant(int v) { g_gauss_march_variant = v; }
+int g_gauss_seg_target = 0; // A/B switch "tune_gaussian_seg": approximate rows per wave segment, 0 = automatic
+void gaussian_set_seg_target(int rows) { g_gauss_seg_target = rows; }
+#endif
 
+#if CANNY_GAUSS_HAS_HOST
 // ---- exhaustive check of div_by against the IEEE divide (test hook) -----------------------------------
 // fma_c == 0: the 5-op div_by;  fma_c != 0 (passed as a bit pattern so that c = 0.0f is expressible through
 // use_fma): the one-instruction candidate a/b ~ fma(a, c, a) used for the full-window weight b = 1 +- ulp.
@@ -870,6 +894,8 @@ hipError_t launch_selftest_div(float b, int use_fma, float c, unsigned first_bit
     return hipGetLastError();
 }
 
+#endif // CANNY_GAUSS_HAS_HOST
+
 // out_u8: 0 = s16 plane, 1 = u8 plane; the u8 form exists for the symmetric-tap kernel with the product table only
 template <int C>
 static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int width, int n_frames,
@@ -878,10 +904,10 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
     using K = MarchCfg<C>;
     if (width < 4) return hipErrorInvalidValue; // the border strips load whole dwords inside a row
     // the symmetric-tap kernel needs tap[C-a] == tap[C+a] bit for bit (true for the reference's taps)
-    bool symmetric = march_variant != 1;
+    bool symmetric = g_gauss_march_variant != 1;
     for (int a = 1; a <= C && symmetric; a++)
         symmetric = std::memcmp(&taps.tap[C - a], &taps.tap[C + a], sizeof(float)) == 0;
-    const bool systolic = symmetric && (march_variant == 0 || march_variant == 4);
+    const bool systolic = symmetric && (g_gauss_march_variant == 0 || g_gauss_march_variant == 4);
     const int strip_w = systolic ? SysCfg<C>::SW : K::SW;
     int n_strips = (width + strip_w - 1) / strip_w;
     // longest segments that still give the chip a few thousand waves; the symmetric kernel processes
@@ -898,14 +924,14 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
     while (target > 8 &&
            (long long)n_frames * n_strips * ((height + seg_for(target) - 1) / seg_for(target)) < 2048)
         target >>= 1;
-    int seg = seg_for(tune_seg_target >= 8 ? tune_seg_target : target);
+    int seg = seg_for(g_gauss_seg_target >= 8 ? g_gauss_seg_target : target);
     // Batches that fill the chip several times over: the waves of a launch run in "rounds" of as many waves as the
     // chip holds (all waves do the same amount of work), and the last round costs a whole round however few waves are
     // left for it.  Pick the segment length that minimises rounds x rows per wave (halo rows included) -- e.g.
     // 128 x 4K at window 11: 144-row segments are 15 per frame = 30720 waves = exactly 6 rounds of 5120, where the
     // 133-row default of the rule above needs 7 rounds (17 segments per frame, the last one 32 rows): 1.069 -> 1.032 ms
     // (profiles/r03/ab4_segments_whole_rounds.txt; 166 rows: 1.120, 100 rows: 1.050, as the model ranks them).
-    if (symmetric && tune_seg_target < 8) {
+    if (symmetric && g_gauss_seg_target < 8) {
         static int n_simds = 0; // SIMDs of the device (4 per CU); one device family, so one value per process
         if (n_simds == 0) {
             int dev = 0, cus = 0;
@@ -946,11 +972,11 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
     int use_fma = 0;
     float fma_c = 0.0f;
     for (const auto &e : kFmaDivTable)
-        if (e[0] == full_bits && fma_div_enabled) {
+        if (e[0] == full_bits && g_gauss_fma_div_enabled) {
             use_fma = 1;
             std::memcpy(&fma_c, &e[1], sizeof(fma_c));
         }
-    const bool table = march_variant == 0 || march_variant == 3;
+    const bool table = g_gauss_march_variant == 0 || g_gauss_march_variant == 3;
     if (out_u8 && !(symmetric && table)) return hipErrorNotSupported;
 #define CANNY_LAUNCH_SYM(LUT, U8, SYS)                                                                                  \
     hipLaunchKernelGGL((gauss_sym_kernel<C, LUT, U8, SYS>), dim3(blocks), dim3(256), 0, stream, img, out, height,     \
@@ -969,6 +995,39 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
     return hipGetLastError();
 }
 
+#define CANNY_GAUSS_CASE(C) \
+    case C: return launch_march_c<C>(img, out, height, width, n_frames, taps, stream, out_u8)
+#if CANNY_GAUSS_PART == 1
+hipError_t launch_gauss_march_part1(int center, const uint8_t *img, void *out, int height, int width, int n_frames,
+                                    const GaussTaps &taps, hipStream_t stream, int out_u8)
+{
+    switch (center) {
+        CANNY_GAUSS_CASE(5);
+        CANNY_GAUSS_CASE(6);
+    default: return hipErrorNotSupported;
+    }
+}
+#elif CANNY_GAUSS_PART == 2
+hipError_t launch_gauss_march_part2(int center, const uint8_t *img, void *out, int height, int width, int n_frames,
+                                    const GaussTaps &taps, hipStream_t stream, int out_u8)
+{
+    switch (center) {
+        CANNY_GAUSS_CASE(7);
+    default: return hipErrorNotSupported;
+    }
+}
+#elif CANNY_GAUSS_PART == 3
+hipError_t launch_gauss_march_part3(int center, const uint8_t *img, void *out, int height, int width, int n_frames,
+                                    const GaussTaps &taps, hipStream_t stream, int out_u8)
+{
+    switch (center) {
+        CANNY_GAUSS_CASE(8);
+    default: return hipErrorNotSupported;
+    }
+}
+#endif
+
+#if CANNY_GAUSS_HAS_HOST
 // (width >= 4: the border strips load whole dwords that must lie inside the row; narrower images take the generic path)
 bool gaussian_march_supported(int center, int, int width) { return center >= 1 && center <= 8 && width >= 4; }
 
@@ -977,16 +1036,23 @@ static hipError_t launch_march_any(const uint8_t *img, void *out, int height, in
 {
     switch (taps.center) {
 #ifdef CANNY_GAUSS_ONLY_C // development aid: compile one window only (-DCANNY_GAUSS_ONLY_C=5) to read its ISA quickly
-    case CANNY_GAUSS_ONLY_C: return launch_march_c<CANNY_GAUSS_ONLY_C>(img, out, height, width, n_frames, taps, stream, out_u8);
+        CANNY_GAUSS_CASE(CANNY_GAUSS_ONLY_C);
 #else
-    case 1: return launch_march_c<1>(img, out, height, width, n_frames, taps, stream, out_u8);
-    case 2: return launch_march_c<2>(img, out, height, width, n_frames, taps, stream, out_u8);
-    case 3: return launch_march_c<3>(img, out, height, width, n_frames, taps, stream, out_u8);
-    case 4: return launch_march_c<4>(img, out, height, width, n_frames, taps, stream, out_u8);
-    case 5: return launch_march_c<5>(img, out, height, width, n_frames, taps, stream, out_u8);
-    case 6: return launch_march_c<6>(img, out, height, width, n_frames, taps, stream, out_u8);
-    case 7: return launch_march_c<7>(img, out, height, width, n_frames, taps, stream, out_u8);
-    case 8: return launch_march_c<8>(img, out, height, width, n_frames, taps, stream, out_u8);
+        CANNY_GAUSS_CASE(1);
+        CANNY_GAUSS_CASE(2);
+        CANNY_GAUSS_CASE(3);
+        CANNY_GAUSS_CASE(4);
+#if CANNY_GAUSS_PART == 0
+    case 5:
+    case 6: return launch_gauss_march_part1(taps.center, img, out, height, width, n_frames, taps, stream, out_u8);
+    case 7: return launch_gauss_march_part2(taps.center, img, out, height, width, n_frames, taps, stream, out_u8);
+    case 8: return launch_gauss_march_part3(taps.center, img, out, height, width, n_frames, taps, stream, out_u8);
+#else
+        CANNY_GAUSS_CASE(5);
+        CANNY_GAUSS_CASE(6);
+        CANNY_GAUSS_CASE(7);
+        CANNY_GAUSS_CASE(8);
+#endif
 #endif
     default: return hipErrorNotSupported;
     }
@@ -1000,7 +1066,7 @@ hipError_t launch_gaussian_march(const uint8_t *img, int16_t *out, int height, i
 
 bool gaussian_march_u8_supported(const GaussTaps &taps)
 {
-    if (taps.center < 1 || taps.center > 8 || (march_variant != 0 && march_variant != 3)) return false;
+    if (taps.center < 1 || taps.center > 8 || (g_gauss_march_variant != 0 && g_gauss_march_variant != 3)) return false;
     for (int a = 1; a <= taps.center; a++)
         if (std::memcmp(&taps.tap[taps.center - a], &taps.tap[taps.center + a], sizeof(float)) != 0) return false;
     return true;
@@ -1011,5 +1077,7 @@ hipError_t launch_gaussian_march_u8(const uint8_t *img, uint8_t *out, int height
 {
     return launch_march_any(img, out, height, width, n_frames, taps, stream, 1);
 }
+#endif // CANNY_GAUSS_HAS_HOST
+#undef CANNY_GAUSS_CASE
 
 } // namespace canny

@@ -720,7 +720,10 @@ __device__ __forceinline__ void gauss_sym_strip(const GaussJob &jb, const GaussT
 // interleaves several rows' products and doubles that.
 template <int C, bool USE_LUT, bool OUT_U8 = false, bool SYS = false>
 // (6 waves per SIMD spill: 2.05 ms against 1.05; 4 compile to the same code as 5 -- profiles/r02/ab4_*.txt)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 5 ? 5 : 4)))
+// (Window 17 -- 68 open sums + 36 products -- does not fit the 128 registers of four waves: 193 spilled registers, and
+// three waves without spills are 3 % faster, 0.945 against 0.971 ms per 64 x 4K.  Window 15 spills five registers at
+// four waves and is still 6 % faster there than at three, 0.772 against 0.825 ms: profiles/r03/ab24_*.txt.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C <= 5 ? 5 : C <= 7 ? 4 : 3)))
 void gauss_sym_kernel(const uint8_t *__restrict__ img, void *__restrict__ out, int H, int W, int n_strips,
                       int n_segs, int seg_rows, int total_waves, GaussTaps t, int use_fma_div, float fma_c)
 {
@@ -941,7 +944,7 @@ static hipError_t launch_march_c(const uint8_t *img, void *out, int height, int 
             n_simds = 4 * cus;
         }
         // waves per SIMD the kernel's registers allow (gauss_sym_kernel<C, true>: 38/49/68/76/95/105/125/128 VGPRs)
-        static const int kWavesPerSimd[9] = {0, 8, 8, 7, 6, 5, 4, 4, 4};
+        static const int kWavesPerSimd[9] = {0, 8, 8, 7, 6, 5, 4, 4, 3};
         const long long slots = (long long)n_simds * kWavesPerSimd[C];
         const long long frames_strips = (long long)n_frames * n_strips;
         if (frames_strips * ((height + seg - 1) / seg) >= 2 * slots) {

@@ -316,17 +316,19 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
     // of the next row, every row; issued behind the wait it has a whole row's time.  (The table-fed kernels also hide
     // their LDS read this way.)
     constexpr bool DEFER = FLT_DEFER_STORE != 0;
+    // (No state beside the pixels: step r parks row r-2 when that row belongs to the segment, so what step r finds
+    // parked is row r-3 -- a test on scalar registers.)
     uint32_t pend[NP] = {};
-    int pend_y = -1; // wave-uniform: the parked row, -1 = none
-    auto park = [&](const uint32_t (&outp)[NP], int y) {
+    auto park = [&](const uint32_t (&outp)[NP]) {
 #pragma unroll
         for (int q = 0; q < NP; q++) pend[q] = outp[q];
-        pend_y = __builtin_amdgcn_readfirstlane(y);
     };
-    auto store_pending = [&]() {
-        if (DEFER && pend_y >= 0) {
-            if (owner) store_row<NP>(jb.fout + (size_t)pend_y * W + x0, pend);
-            pend_y = -1;
+    // the instantiations that park: the staged-plane kernels, and the plain kernels away from the column borders (there
+    // a lane may own part of a row and stores pixel by pixel, at once)
+    constexpr bool PARKS = DEFER && ((PLANES && STAGE) || (!PLANES && !COL_EDGE));
+    auto store_pending = [&](int y) { // y: the row that is parked if any row is
+        if (PARKS && y >= ybeg && y < yend) {
+            if (owner) store_row<NP>(jb.fout + (size_t)y * W + x0, pend);
         }
     };
 
@@ -348,7 +350,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
 #pragma unroll
             for (int i = 0; i < NP; i++) asm volatile("" : "+v"(p[i]));
             __builtin_amdgcn_sched_barrier(0);
-            store_pending();
+            store_pending(r - 3);
             __builtin_amdgcn_sched_barrier(0);
         }
         constexpr int k2 = PH % 3, k1 = (PH + 2) % 3, k0 = (PH + 1) % 3; // d/t of rows r, r-1, r-2
@@ -485,7 +487,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                     stage[rowoff + stage_col] = (uint8_t)cbits; // halo lanes write pad columns nobody reads
                     stage[kStagePlane + rowoff + stage_col] = (uint8_t)sb;
                     if (DEFER)
-                        park(outp, y2);
+                        park(outp);
                     else if (owner)
                         store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                 } else if (owner) { // W % 8 == 0: an owner lane's pixels are all inside the image
@@ -499,7 +501,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
                     store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                 }
             } else if (DEFER && !COL_EDGE) {
-                park(outp, y2); // interior strips: every owner lane stores whole rows
+                park(outp); // interior strips: every owner lane stores whole rows
             } else if (owner) {
                 int16_t *dst = jb.fout + (size_t)y2 * W + x0;
                 if (!COL_EDGE || full8) {
@@ -529,7 +531,7 @@ __device__ __forceinline__ void march_strip(const StripJob &jb, uint8_t *stage_m
         load_row(r + 4, pb);
         step(IC<2>{}, r + 2, pc);
     }
-    store_pending();
+    store_pending(rlast - 2);
     // Every row below yend has been staged by now; the row loop's state is dead here, so the flush's own
     // registers come for free (called from inside the loop it pushed the kernel from 160 to 215 VGPRs).
     if (STAGE) stage_flush_segment();
@@ -701,17 +703,19 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
 
     // DEFER: see march_strip -- a row's output pixels are parked and stored at the top of the next row's step.
     constexpr bool DEFER = FLT_DEFER_STORE != 0;
+    // (No state beside the pixels: step r parks row r-2 when that row belongs to the segment, so what step r finds
+    // parked is row r-3 -- a test on scalar registers.)
     uint32_t pend[NP] = {};
-    int pend_y = -1; // wave-uniform: the parked row, -1 = none
-    auto park = [&](const uint32_t (&outp)[NP], int y) {
+    auto park = [&](const uint32_t (&outp)[NP]) {
 #pragma unroll
         for (int q = 0; q < NP; q++) pend[q] = outp[q];
-        pend_y = __builtin_amdgcn_readfirstlane(y);
     };
-    auto store_pending = [&]() {
-        if (DEFER && pend_y >= 0) {
-            if (owner) store_row<NP>(jb.fout + (size_t)pend_y * W + x0, pend);
-            pend_y = -1;
+    // the instantiations that park: the staged-plane kernels, and the plain kernels away from the column borders (there
+    // a lane may own part of a row and stores pixel by pixel, at once)
+    constexpr bool PARKS = DEFER && ((PLANES && STAGE) || (!PLANES && !COL_EDGE));
+    auto store_pending = [&](int y) { // y: the row that is parked if any row is
+        if (PARKS && y >= ybeg && y < yend) {
+            if (owner) store_row<NP>(jb.fout + (size_t)y * W + x0, pend);
         }
     };
 
@@ -735,7 +739,7 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
 #pragma unroll
             for (int e = 0; e < PX; e++) asm volatile("" : "+v"(F[k2][e]));
             FLT_SCHED_FENCE();
-            store_pending();
+            store_pending(r - 3);
             FLT_SCHED_FENCE();
         }
         // EARLY: the row's raw pixels are converted, so their registers can take row r+3 at once -- three rows in
@@ -853,7 +857,7 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
                     stage[rowoff + stage_col] = (uint8_t)cbits; // halo lanes write pad columns nobody reads
                     stage[kStagePlane + rowoff + stage_col] = (uint8_t)sb;
                     if (DEFER)
-                        park(outp, y2);
+                        park(outp);
                     else if (owner)
                         store_row<NP>(jb.fout + (size_t)y2 * W + x0, outp);
                 } else {
@@ -873,7 +877,7 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
             } else if (DEFER && !COL_EDGE) {
 #pragma unroll
                 for (int i = 0; i < NP; i++) outp[i] = (uint32_t)keep[2 * i] | ((uint32_t)keep[2 * i + 1] << 16);
-                park(outp, y2); // interior strips: every owner lane stores whole rows
+                park(outp); // interior strips: every owner lane stores whole rows
             } else if (owner) {
 #pragma unroll
                 for (int i = 0; i < NP; i++) outp[i] = (uint32_t)keep[2 * i] | ((uint32_t)keep[2 * i + 1] << 16);
@@ -911,7 +915,7 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
             step(IC<2>{}, r + 2, pc);
         }
     }
-    store_pending();
+    store_pending(rlast - 2);
     if (STAGE) stage_flush_segment();
 }
 

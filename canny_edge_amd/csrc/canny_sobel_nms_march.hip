@@ -602,11 +602,20 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
     for (int e = 0; e <= PX; e++) in_m[e] = COL_EDGE ? (e - 1 - elast) >> 31 : -1;
     auto inside = [&](int e) { return in_m[e]; }; // all ones iff x0 + e lies inside the image
 
+    // Lane offset (in pixels) of the interior strips' row loads and stores, passed through an empty asm at every use so
+    // that the optimiser cannot fold it into loop-invariant 64-bit VGPR pointers (as in the Gaussian: the addresses stay
+    // "uniform row base + 32-bit lane offset").  Interior strips have x0 >= 0.
+    uint32_t lane_off = (uint32_t)x0;
     auto load_row = [&](int r, uint32_t (&p)[NP]) {
 #pragma unroll
         for (int i = 0; i < NP; i++) p[i] = 0u;
         if (ROW_EDGE && (r < 0 || r >= H)) return; // wave-uniform: virtual rows are zero
         if (IN_U8) {
+            if (!COL_EDGE) { // uniform row base (SGPR pair) + 32-bit lane offset: no 64-bit address arithmetic per lane
+                asm volatile("" : "+v"(lane_off));
+                __builtin_memcpy(p, jb.fin8 + (size_t)r * W + lane_off, 8);
+                return;
+            }
             const uint8_t *src8 = jb.fin8 + (size_t)r * W + x0;
             if (!COL_EDGE || full8) {
                 __builtin_memcpy(p, src8, 8); // one 8-byte load
@@ -617,6 +626,11 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
                     if (x >= 0 && x < W) p[e >> 2] |= (uint32_t)src8[e] << (8 * (e & 3));
                 }
             }
+            return;
+        }
+        if (!COL_EDGE) {
+            asm volatile("" : "+v"(lane_off));
+            __builtin_memcpy(p, reinterpret_cast<const char *>(jb.fin + (size_t)r * W) + 2 * lane_off, 4 * NP);
             return;
         }
         const int16_t *src = jb.fin + (size_t)r * W + x0;
@@ -715,7 +729,14 @@ __device__ __forceinline__ void fmarch_strip(const StripJob &jb, uint8_t *stage_
     constexpr bool PARKS = DEFER && ((PLANES && STAGE) || (!PLANES && !COL_EDGE));
     auto store_pending = [&](int y) { // y: the row that is parked if any row is
         if (PARKS && y >= ybeg && y < yend) {
-            if (owner) store_row<NP>(jb.fout + (size_t)y * W + x0, pend);
+            if (!COL_EDGE) {
+                asm volatile("" : "+v"(lane_off));
+                if (owner)
+                    store_row<NP>(reinterpret_cast<int16_t *>(reinterpret_cast<char *>(jb.fout + (size_t)y * W) +
+                                                              2 * lane_off), pend);
+            } else if (owner) {
+                store_row<NP>(jb.fout + (size_t)y * W + x0, pend);
+            }
         }
     };
 

@@ -3,8 +3,10 @@
 // Two kernels with the same decomposition (one WAVE owns a strip of (64-2*HL)*4 output columns and marches
 // down a segment of rows, row and column pass in one kernel, the f32 intermediate never leaves the CU):
 //   * gauss_sym_kernel  (default, see the comment above gauss_sym_strip): needs bit-symmetric taps; each
-//     rounded product serves two outputs, the row pass looks its products up in an LDS table and exchanges
-//     them between lanes with DPP, the column pass keeps 2C+1 running sums in registers;
+//     rounded product serves two outputs, the row pass looks its products up in an LDS table and -- since
+//     round 3, "SYS" -- passes the running sums from lane to lane with DPP adds (the earlier form, which
+//     fetches the neighbours' products instead, is still there for A/B), the column pass keeps 2C+1 running
+//     sums in registers;
 //   * gauss_march_kernel (below; fallback for asymmetric taps and A/B): LDS row buffer + LDS column ring.
 //
 // gauss_march_kernel: the waves of a workgroup are independent (no __syncthreads anywhere).  Per input row:

@@ -18,7 +18,10 @@
 //       threshold floor of the PLANES kernel), which never changes an output (= "skip", see `skip` below).
 // Three rows of d/t, of magnitudes and of bin discriminants rotate through registers; the row loop is
 // unrolled by 3 so that every rotation is a compile-time renaming and the three prefetched rows never
-// have to be copied while their loads are in flight.
+// have to be copied while their loads are in flight.  A row's output pixels are stored one step late, at the
+// top of the next row's step (DEFER below: loads and stores share the vmcnt counter), and the launch takes a
+// frame's border cells first (march_cell_of, canny_kernels.h).  The f32 arithmetic canny() runs since round 3
+// is fmarch_strip, further down; the description here is the packed-i16 form of the stage kernel.
 //
 // Border conventions of the reference (src/utils.cpp:114-186, 248-308):
 //   gx: column clamp  -> zero-filled neighbours plus a +-s fix-up at columns 0 and W-1; rows dropped
